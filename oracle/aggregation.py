@@ -1,0 +1,190 @@
+"""Oracle (TEST INFRASTRUCTURE): fp64 numpy restatement of the float aggregation path.
+
+PARITY UNPINNED at the third-party boundary (see oracle/__init__.py): torch_scatter,
+torch_sparse, torch_geometric and tensorflow are absent and the reference stores no outputs
+for them.  Restated from the published definitions of the pinned versions
+(requirements.txt:1,18-20), anchored on the reference's call sites, which are cited per
+function.  Everything runs in float64 so the HIP fp32 path can be held to 1e-5 relative.
+"""
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- scatter / spmm
+def scatter_add(src, index, dim_size=None, dtype=None):
+    """torch_scatter.scatter_add(src, index, dim=0, dim_size=N) [3P, torch-scatter 2.1.1]
+    as called at TwoWL/utils.py:10: out = zeros(N, ...); out[index[e]] += src[e]."""
+    src = np.asarray(src)
+    index = np.asarray(index, dtype=np.int64)
+    n = int(dim_size) if dim_size is not None else (int(index.max()) + 1 if index.size else 0)
+    out = np.zeros((n,) + src.shape[1:], dtype=dtype or src.dtype)
+    np.add.at(out, index, src)
+    return out
+
+
+def coo_to_csr(row, col, n_rows, val=None):
+    """stable sort by row -> (rowptr[n+1], col, val, perm); within a row the original edge
+    order is kept (the order torch's CPU scatter_add_ accumulates in)."""
+    row = np.asarray(row, dtype=np.int64)
+    perm = np.argsort(row, kind="stable")
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(row, minlength=n_rows), out=rowptr[1:])
+    col = np.asarray(col, dtype=np.int64)[perm]
+    val = None if val is None else np.asarray(val)[perm]
+    return rowptr, col, val, perm
+
+
+def csr_spmm(rowptr, col, val, x, row_scale=None, bias=None, act=None):
+    """Y = act(row_scale * (A @ X) + bias), A in CSR; float64.
+    torch_sparse.spmm / matmul(reduce='sum') [3P, torch-sparse 0.6.17]; SEAL's
+    tanh(D^-1 (A~ (XW))) at SEAL/model/gnn.py:47-48 is row_scale = D^-1, act = tanh."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(rowptr) - 1
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    msg = x[np.asarray(col, dtype=np.int64)]
+    if val is not None:
+        msg = msg * np.asarray(val, dtype=np.float64)[:, None]
+    y = np.zeros((n, x.shape[1]), dtype=np.float64)
+    np.add.at(y, rows, msg)
+    if row_scale is not None:
+        y = y * np.asarray(row_scale, dtype=np.float64)[:, None]
+    if bias is not None:
+        y = y + np.asarray(bias, dtype=np.float64)[None, :]
+    if act == "tanh":
+        y = np.tanh(y)
+    elif act == "relu":
+        y = np.maximum(y, 0.0)
+    return y
+
+
+def spmm_abs_rowsum(rowptr, col, val, x):
+    """sum_e |w_e x_e| per output element: the scale the 1e-5 tolerance is relative to."""
+    v = None if val is None else np.abs(val)
+    return csr_spmm(rowptr, col, v, np.abs(np.asarray(x, dtype=np.float64)))
+
+
+# ----------------------------------------------------------------------------- GCNConv pieces
+def add_remaining_self_loops(edge_index, edge_weight, n, fill_value=1.0):
+    """torch_geometric.utils.add_remaining_self_loops [3P, PyG 2.3.1], used by gcn_norm:
+    existing self loops are REMOVED from the edge list and every node gets exactly one loop,
+    appended after the non-loop edges, weight = the node's existing loop weight (the last one
+    if several) else fill_value."""
+    ei = np.asarray(edge_index, dtype=np.int64)
+    w = np.ones(ei.shape[1], dtype=np.float64) if edge_weight is None else np.asarray(edge_weight, dtype=np.float64)
+    mask = ei[0] != ei[1]
+    loop_w = np.full(n, fill_value, dtype=np.float64)
+    inv = ~mask
+    loop_w[ei[0][inv]] = w[inv]          # sequential assignment: last one wins
+    loops = np.arange(n, dtype=np.int64)
+    ei2 = np.concatenate([ei[:, mask], np.stack([loops, loops])], axis=1)
+    return ei2, np.concatenate([w[mask], loop_w])
+
+
+def gcn_norm(edge_index, n, edge_weight=None):
+    """torch_geometric.nn.conv.gcn_conv.gcn_norm [3P] with the defaults GCNConv(insize,
+    outsize) uses at TwoWL/model/model.py:37 (improved=False, add_self_loops=True,
+    flow='source_to_target'): deg by DESTINATION (row 1); w' = deg^-1/2[src] w deg^-1/2[dst],
+    inf -> 0."""
+    ei, w = add_remaining_self_loops(edge_index, edge_weight, n, 1.0)
+    deg = np.zeros(n, dtype=np.float64)
+    np.add.at(deg, ei[1], w)
+    with np.errstate(divide="ignore"):
+        dinv = deg ** -0.5
+    dinv[np.isinf(dinv)] = 0.0
+    return ei, dinv[ei[0]] * w * dinv[ei[1]]
+
+
+def gcn_conv(x, edge_index, weight, bias, edge_weight=None):
+    """GCNConv.forward [3P]: out = A_hat (x W^T) + b; out[dst] += w' * h[src]
+    (call sites TwoWL/model/model.py:73,77).  weight is [out,in] as nn.Linear stores it."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    h = x @ np.asarray(weight, dtype=np.float64).T
+    ei, w = gcn_norm(edge_index, n, edge_weight)
+    out = np.zeros((n, h.shape[1]), dtype=np.float64)
+    np.add.at(out, ei[1], h[ei[0]] * w[:, None])
+    if bias is not None:
+        out = out + np.asarray(bias, dtype=np.float64)[None, :]
+    return out
+
+
+def graph_norm(x, weight, bias, mean_scale, eps=1e-5):
+    """torch_geometric.nn.GraphNorm.forward(x, batch=None) [3P] (TwoWL/model/model.py:38,54;
+    single graph because Seq.forward passes only `out` on, :92-96):
+    o = x - mean * mean_scale;  y = weight * o / sqrt(mean(o^2) + eps) + bias   (column-wise)."""
+    x = np.asarray(x, dtype=np.float64)
+    mean = x.mean(axis=0, keepdims=True)
+    o = x - mean * np.asarray(mean_scale, dtype=np.float64)[None, :]
+    var = (o * o).mean(axis=0, keepdims=True)
+    return np.asarray(weight, dtype=np.float64)[None, :] * o / np.sqrt(var + eps) + np.asarray(bias, dtype=np.float64)[None, :]
+
+
+# ----------------------------------------------------------------------------- TwoWL forward
+def pair_hadamard(x, pos):
+    """TwoWL/model/model.py:75 -- h[t] = x[pos[t,0]] * x[pos[t,1]]."""
+    pos = np.asarray(pos, dtype=np.int64)
+    return x[pos[:, 0]] * x[pos[:, 1]]
+
+
+def pair_readout(h, idx, w, b):
+    """TwoWL/model/model.py:78-83 -- x = h[idx]; s = Linear(x[even] * x[odd])."""
+    idx = np.asarray(idx, dtype=np.int64)
+    xx = h[idx]
+    z = xx[0::2] * xx[1::2]
+    return z @ np.asarray(w, dtype=np.float64).T + np.asarray(b, dtype=np.float64)[None, :]
+
+
+def localwl_forward(params, x_deg, edge1, pos, idx, ei2):
+    """LocalWLNet.forward in eval mode (TwoWL/model/model.py:68-84; dropout = identity).
+    params: dict from lpgnn_amd.twowl.LocalWLNet.export_params() (plain numpy arrays)."""
+    from .twowl_int import reverse
+    edge2, edge2_r = reverse(ei2)
+    p = params
+    x = np.asarray(p["emb.weight"], dtype=np.float64)[np.asarray(x_deg, dtype=np.int64)]
+    x = graph_norm(x, p["emb_norm.weight"], p["emb_norm.bias"], p["emb_norm.mean_scale"])
+    for l in range(p["depth1"]):
+        x = gcn_conv(x, edge1, p[f"conv1s.{l}.lin.weight"], p[f"conv1s.{l}.bias"])
+        x = graph_norm(x, p[f"conv1s.{l}.norm.weight"], p[f"conv1s.{l}.norm.bias"], p[f"conv1s.{l}.norm.mean_scale"])
+        if p[f"conv1s.{l}.act"]:
+            x = np.maximum(x, 0.0)
+    x = pair_hadamard(x, pos)
+    for l in range(p["depth2"]):
+        outs = []
+        for name, e in (("conv2s", edge2), ("conv2s_r", edge2_r)):
+            y = gcn_conv(x, e, p[f"{name}.{l}.lin.weight"], p[f"{name}.{l}.bias"])
+            y = graph_norm(y, p[f"{name}.{l}.norm.weight"], p[f"{name}.{l}.norm.bias"], p[f"{name}.{l}.norm.mean_scale"])
+            outs.append(np.maximum(y, 0.0))
+        x = outs[0] + outs[1]
+    return pair_readout(x, idx, p["pred.weight"], p["pred.bias"])
+
+
+# ----------------------------------------------------------------------------- SEAL graph conv
+def seal_graph_conv(a_tilde, d_inv, x, weights):
+    """SEAL/model/gnn.py:46-63 -- Z_l = tanh(D^-1 (A~ (Z_{l-1} W_l))) for l = 1..4 on ONE
+    subgraph (dense operands as the reference feeds them); returns (concat(Z1,Z2,Z3), Z4[:,0])."""
+    a = np.asarray(a_tilde, dtype=np.float64)
+    d = np.asarray(d_inv, dtype=np.float64)
+    z = np.asarray(x, dtype=np.float64)
+    zs = []
+    for w in weights:
+        z = np.tanh(d[:, None] * (a @ (z @ np.asarray(w, dtype=np.float64))))
+        zs.append(z)
+    return np.concatenate(zs[:3], axis=1), zs[3][:, 0]
+
+
+def auc(y_true, score):
+    """rank-based ROC AUC (ties get average rank) == sklearn.metrics.roc_auc_score used at
+    TwoWL/model/train.py:66 and SEAL/operators/seal_link_predict.py:91."""
+    y = np.asarray(y_true).reshape(-1).astype(bool)
+    s = np.asarray(score, dtype=np.float64).reshape(-1)
+    order = np.argsort(s, kind="mergesort")
+    ranks = np.empty(len(s), dtype=np.float64)
+    ss = s[order]
+    i = 0
+    while i < len(ss):
+        j = i
+        while j + 1 < len(ss) and ss[j + 1] == ss[i]:
+            j += 1
+        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    npos, nneg = y.sum(), (~y).sum()
+    return (ranks[y].sum() - npos * (npos + 1) / 2.0) / (npos * nneg)
