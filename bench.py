@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the aggregation hot path on MI355X.
+
+Workload (config.workload): the north star's single-GPU target instance, SURVEY.md section 8d
+config 5 scaled as the north star states it: synthetic RMAT (a,b,c,d = 0.57,0.19,0.19,0.05,
+seed 5) CSR graph, |V| = 5 M, |E| = 100 M directed nnz (duplicates kept), unweighted, fp32
+features d = 128;  one "step" = one CSR-SpMM pass Y = A @ X over the whole graph (all three
+kernels of lpg_csr_spmm_f32) with graph, plan and X already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the north star's
+source-edge partition -- rank g owns source rows [g*V/N, (g+1)*V/N) of X and the |E| = 100 M
+edges that leave them (weak scaling: per-GPU edges fixed), computes a partial Y_g[V, d] and the
+partials are summed with an RCCL all-reduce, row-block pipelined against the SpMM of the next
+block.  value = edges aggregated by ALL ranks per second (max-over-ranks time).
+
+Prints ONE JSON line (rank 0).  Extra objects: roofline (HBM, dominant kernel), cpu_baseline
+(the torch_scatter CPU path restated, bounded sample, N = 1 only), twowl (the reference's own
+recorded metric: fb-pages-food test-split scoring forward, scored edges/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured copy ceiling
+RMAT = (0.57, 0.19, 0.19, 0.05)
+
+
+def rmat_edges(n_nodes, n_edges, seed, device, src_range=None):
+    """RMAT edge list [2, E] int64 (row 0 = source, row 1 = destination), generated on `device`.
+    src_range=(lo, hi) maps sources into that node range (source-edge partition)."""
+    a, b, c, _ = RMAT
+    bits = max(1, (n_nodes - 1).bit_length())
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    src = torch.zeros(n_edges, dtype=torch.int64, device=device)
+    dst = torch.zeros(n_edges, dtype=torch.int64, device=device)
+    for _ in range(bits):
+        r = torch.rand(n_edges, generator=gen, device=device)
+        sbit = r >= (a + b)
+        dbit = ((r >= a) & (r < a + b)) | (r >= a + b + c)
+        src = src * 2 + sbit
+        dst = dst * 2 + dbit
+        del r, sbit, dbit
+    src %= n_nodes
+    dst %= n_nodes
+    if src_range is not None:
+        lo, hi = src_range
+        src = lo + src % (hi - lo)
+    return torch.stack([src, dst])
+
+
+def make_rmat_problem(n_nodes, n_edges, d, seed, device, dtype=torch.float32, src_range=None):
+    """(CSRGraph over destination rows, X).  With src_range, X holds only the owned source rows
+    and column ids are local to the range."""
+    import lpgnn_amd
+    ei = rmat_edges(n_nodes, n_edges, seed, device, src_range)
+    n_cols = n_nodes
+    if src_range is not None:
+        ei[0] -= src_range[0]
+        n_cols = src_range[1] - src_range[0]
+    g = lpgnn_amd.CSRGraph.from_edge_index(ei, n_nodes, n_cols)
+    del ei
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1000)
+    x = torch.randn((n_cols, d), generator=gen, device=device, dtype=torch.float32).to(dtype)
+    return g, x
+
+
+def spmm_algorithmic_bytes(n_rows, n_edges, d, elt=4, weighted=False):
+    """SURVEY.md section 8d per-edge gather model: E*(4 [+4] + d*s) + (N+1)*8 + N*d*s."""
+    return n_edges * (4 + (4 if weighted else 0) + d * elt) + (n_rows + 1) * 8 + n_rows * d * elt
+
+
+def cpu_baseline(d, seconds_budget=20.0):
+    """The reference's CPU aggregation path restated (torch_scatter.scatter_add == ATen
+    scatter_add_ after the PyG message gather x[src]) on a bounded sample of the same generator:
+    |V| = 500 K, |E| = 10 M, d = 128.  Reported, not the target."""
+    n, e = 500_000, 10_000_000
+    ei = rmat_edges(n, e, 5, "cpu")
+    x = torch.randn((n, d))
+    src, dst = ei[0], ei[1]
+    torch.set_num_threads(os.cpu_count() or 1)
+    idx = dst.view(-1, 1).expand(-1, d)
+
+    def run():
+        msg = x[src]
+        return torch.zeros((n, d)).scatter_add_(0, idx, msg)
+
+    run()
+    best, t_all = None, time.time()
+    for _ in range(3):
+        t0 = time.time()
+        run()
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+        if time.time() - t_all > seconds_budget:
+            break
+    # the torch_sparse stand-in (CSR SpMM on the host), for context
+    order = torch.argsort(dst, stable=True)
+    crow = torch.zeros(n + 1, dtype=torch.int64)
+    crow[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0)
+    A = torch.sparse_csr_tensor(crow, src[order], torch.ones(e), size=(n, n))
+    A @ x
+    t0 = time.time()
+    A @ x
+    t_csr = time.time() - t0
+    return {"value": e / best, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"RMAT |V|={n} |E|={e} d={d} fp32, x[src] + zeros.scatter_add_ (torch_scatter path), best of 3",
+            "csr_spmm_edges_per_s": e / t_csr, "host_cpus": os.cpu_count()}
+
+
+def twowl_forward_bench(device, iters=50):
+    """The reference's own recorded metric (records_auc/*twowl.txt 'Time'): the test-split
+    scoring forward on fb-pages-food (N=620, E1=3480, P=4252, E2=69525, B=386), model defaults
+    C1=256, C2=32, depth 1/1 (TwoWL/model/model.py:13-16).  Real split from tests/golden."""
+    import numpy as np
+    from lpgnn_amd import twowl
+    z = np.load(os.path.join(ROOT, "tests", "golden", "twowl_int.npz"))
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(device)
+    ei, pred, ei2 = t(z["test_ei"]), t(z["test_pred"]), t(z["test_ei2"])
+    x_deg = twowl.degree(t(z["val_ei"]), 620)
+    pos1 = torch.cat([ei.t(), pred.t()], 0).contiguous()
+    torch.manual_seed(0)
+    mod = twowl.LocalWLNet(int(x_deg.max())).to(device).eval()
+    y_len = pred.shape[1]
+    for _ in range(5):
+        twowl.test_forward(mod, x_deg, ei, pos1, y_len, ei2)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(iters):
+        twowl.test_forward(mod, x_deg, ei, pos1, y_len, ei2)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / iters
+    return {"workload": "fb-pages-food TwoWL test-split scoring forward fp32 (configs[1])", "scored_edges": y_len // 2,
+            "us_per_forward": dt * 1e6, "scored_edges_per_s": (y_len // 2) / dt,
+            "reference_recorded_s_per_forward": [0.0698, 0.1361]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nodes", type=int, default=5_000_000)
+    ap.add_argument("--edges", type=int, default=100_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--blocks", type=int, default=8, help="row blocks for compute/all-reduce overlap (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-twowl", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import lpgnn_amd
+    lpgnn_amd.load_library()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    elt = 4 if args.dtype == "f32" else 2
+    N, E, d = args.nodes, args.edges, args.dim
+
+    t_build = time.time()
+    if world == 1:
+        g, x = make_rmat_problem(N, E, d, seed=5, device=device, dtype=dtype)
+        runner = None
+    else:
+        from lpgnn_amd import dist as ldist
+        lo, hi = ldist.source_range(N, world, rank)
+        ei = rmat_edges(N, E, 5 + rank, device, src_range=(lo, hi))
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1005 + rank)
+        x = torch.randn((hi - lo, d), generator=gen, device=device).to(dtype)
+        runner = ldist.SourcePartitionedSpMM(ei, N, (lo, hi), n_blocks=args.blocks)
+        del ei
+        g = None
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+
+    def step():
+        if runner is None:
+            return g.spmm(x)
+        return runner.forward(x)
+
+    for _ in range(args.warmup):
+        y = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()                         # kernels are launched on torch's current stream
+    for i in range(args.steps):
+        y = step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per_step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    kern_ms = sum(per_step_ms) / len(per_step_ms)
+    nnz = g.nnz() if g is not None else E
+    total_edges = nnz * world
+    value = total_edges * args.steps / elapsed
+
+    out = {
+        "metric": "aggregated edges/sec (CSR-SpMM forward, the SEAL/2-WL aggregation hot path)",
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"RMAT(0.57,0.19,0.19,0.05) CSR-SpMM |V|={N} |E|={E}/GPU d={d} {args.dtype}, unweighted, "
+                               "int32 col / int64 rowptr; north_star 1-GPU target instance (SURVEY 8d config 5 generator, seed 5)",
+                   "parallelism": "single GPU" if world == 1 else f"source-edge partition x{world} + RCCL all-reduce of Y[V,d] "
+                                                                    f"({args.blocks} row blocks, overlapped)",
+                   "graph_build_s": t_build},
+    }
+    if rank == 0:
+        if world == 1:
+            alg = spmm_algorithmic_bytes(N, nnz, d, elt)
+            ach = alg / (kern_ms * 1e-3) / 1e9
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tj):
+                try:
+                    tr = json.load(open(tj))
+                    if tr.get("workload") == [N, E, d, args.dtype]:
+                        traffic = tr.get("hbm_bytes_per_step")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "lpg_csr_spmm (spmm_main_kernel + spmm_fixup_kernel + spmm_empty_rows_kernel, "
+                                         "HIP-event time of the whole call on the launch stream)",
+                               "algorithmic_bytes_per_step": alg, "avg_launch_ms": kern_ms,
+                               "frac_of_measured_copy_ceiling_6290": ach / 6290.0}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(d)
+            if not args.no_twowl:
+                try:
+                    out["twowl"] = twowl_forward_bench(device)
+                except Exception as e:       # secondary figure must never take the headline down
+                    out["twowl"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

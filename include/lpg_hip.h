@@ -1,0 +1,198 @@
+/*
+ * lpg_hip.h -- C ABI of liblpg_hip.so: MI355X (gfx950 / CDNA4) message-passing aggregation
+ * kernels behind the torch_scatter / torch_sparse / PyG-GCNConv call signatures used by
+ * NguyenTrieu903/Link-Prediction-GNN (reference file:line cited per entry point; paths are
+ * relative to the reference repo root).
+ *
+ * The reference has NO FFI of its own for this path: its boundary is the Python operator API of
+ * three third-party wheels.  This header is therefore the ABI those
+ * Python signatures bind to in this build; INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor) unless marked "host";
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work,
+ *    they never synchronise unless the comment says "syncs";
+ *  - no allocation inside: scratch comes from the caller, sized by the matching *_bytes() query;
+ *  - return value: 0 = ok, <0 = error (LPG_E_*); text via lpg_last_error() (thread-local);
+ *  - index tensors are int64 at the API (PyG convention) and narrowed to int32 once per graph;
+ *  - `err_flag` (int32 on device, caller-zeroed) is OR-ed with LPG_F_* bits by kernels that take
+ *    user indices; out-of-range indices are SKIPPED (never dereferenced) and flagged.
+ */
+#ifndef LPG_HIP_H
+#define LPG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPG_ABI_VERSION 1
+
+#define LPG_OK 0
+#define LPG_E_INVALID (-1)   /* bad argument (null pointer, negative size, misalignment) */
+#define LPG_E_LAUNCH (-2)    /* hip launch / runtime error */
+#define LPG_E_WORKSPACE (-3) /* workspace too small */
+#define LPG_E_UNSUPPORTED (-4)
+
+#define LPG_F_INDEX_RANGE 1 /* an index was outside [0, limit) */
+
+#define LPG_ACT_NONE 0
+#define LPG_ACT_RELU 1
+#define LPG_ACT_TANH 2
+
+const char* lpg_last_error(void);
+int lpg_abi_version(void);
+/* edges per work chunk of the chunked SpMM (needed to size workspaces on the host) */
+int lpg_spmm_chunk_edges(void);
+
+/* ---------------------------------------------------------------- scatter_add (K1, K2)
+ * torch_scatter.scatter_add(src, index, dim=0, out=None, dim_size=N)   [TwoWL/utils.py:5,10]
+ * out[index[e], :] += src[e, :].  `out` is accumulated into (caller zeroes it when out=None).
+ * i64: src == NULL means "ones" (the degree() call).  Integer adds commute => bit-exact.
+ * f32: global_atomic_add_f32, row-contiguous; order of adds is not fixed (use the CSR path for
+ *      a reproducible sum). */
+int lpg_scatter_add_i64(const int64_t* src, const int64_t* index, int64_t E, int64_t d,
+                        int64_t* out, int64_t N, int32_t* err_flag, void* stream);
+int lpg_scatter_add_f32(const float* src, const int64_t* index, int64_t E, int64_t d,
+                        float* out, int64_t N, int32_t* err_flag, void* stream);
+
+/* ---------------------------------------------------------------- COO -> CSR (once per graph)
+ * Stable sort of the E edges by destination `dst` (row of the CSR): inside a row the original
+ * edge order is kept, which is the order torch's CPU scatter_add_ accumulates in.
+ * gcn_self_loops != 0 reproduces torch_geometric add_remaining_self_loops as gcn_norm calls it
+ * [PyG 2.3.1; call sites TwoWL/model/model.py:37,73,77]: existing self loops are dropped and one
+ * loop per node is appended after the row's other edges (weight = the node's last existing loop
+ * weight if `val` is given, else fill 1).  Capacity of col_out/val_out/perm_out: E (+ N with
+ * self loops).  The number of stored edges is rowptr[N] (device value).
+ * perm_out[k] = original edge id of CSR slot k (>= E for appended loops); may be NULL. */
+int64_t lpg_coo_to_csr_bytes(int64_t E, int64_t N, int gcn_self_loops);
+int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const float* val, int64_t E,
+                   int64_t n_rows, int64_t n_cols, int gcn_self_loops,
+                   int64_t* rowptr, int32_t* col_out, float* val_out, int32_t* perm_out,
+                   void* workspace, int64_t workspace_bytes, int32_t* err_flag, void* stream);
+
+/* gcn_norm on the dst-major CSR [PyG gcn_norm; TwoWL/model/model.py:37]:
+ * deg[j] = sum of row j's weights; dinv = deg^-1/2 (inf -> 0);
+ * val[k] = dinv[col[k]] * val[k] * dinv[row(k)]  (in place; val == ones when unweighted). */
+int lpg_gcn_norm_csr(const int64_t* rowptr, const int32_t* col, float* val, float* dinv,
+                     int64_t N, void* stream);
+
+/* ---------------------------------------------------------------- SpMM plan (once per graph)
+ * Expands rowptr into a per-edge row-id stream and lists the empty rows, so the SpMM kernels
+ * need no dependent rowptr walks.  Checks 0 <= col < n_cols (err_flag).  e_cap = capacity of
+ * the col array (>= rowptr[N]). */
+int64_t lpg_csr_plan_bytes(int64_t N, int64_t e_cap);
+int lpg_csr_plan_build(const int64_t* rowptr, const int32_t* col, int64_t N, int64_t n_cols,
+                       int64_t e_cap, void* plan, int64_t plan_bytes, int32_t* err_flag,
+                       void* stream);
+
+/* ---------------------------------------------------------------- CSR SpMM (K4, K10) -- hot
+ * Y[N,d] = act( row_scale[:,None] * (A @ X) + bias[None,:] ),  A = (rowptr, col, val) dst-major.
+ * torch_sparse.spmm / matmul(reduce="sum") and the propagate step of GCNConv
+ * [TwoWL/model/model.py:73,77]; with row_scale = D^-1, act = tanh it is SEAL's
+ * tanh(D^-1 (A~ (X W)))  [SEAL/model/gnn.py:47-48,51-52,55-56,59-60].
+ * val == NULL: all ones.  row_scale / bias may be NULL.  ldx/ldy = row strides in elements.
+ * Atomic-free and bitwise reproducible: edges are cut into fixed chunks, rows that straddle
+ * chunks are finished by a second kernel that adds the partials in chunk order.
+ * bf16 variant: x, y are bfloat16 (uint16 bit patterns), accumulation in fp32. */
+int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d);
+int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col,
+                     const float* val, const float* x, int64_t ldx, float* y, int64_t ldy,
+                     int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
+                     const float* bias, int act, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* col,
+                      const float* val, const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy,
+                      int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
+                      const float* bias, int act, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
+/* ---------------------------------------------------------------- dense feature linear (K5)
+ * Y[n,m] = X[n,k] @ W^T (+ bias), W is [m,k] (nn.Linear / GCNConv.lin layout) or, with
+ * w_is_km != 0, [k,m] (SEAL's tf.matmul(X, W), SEAL/model/gnn.py:46,50,54,58).
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products). */
+int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias,
+                   float* y, int64_t ldy, int64_t n, int64_t k, int64_t m, void* stream);
+
+/* ---------------------------------------------------------------- GraphNorm (K6)
+ * torch_geometric.nn.GraphNorm.forward(x, batch=None) [TwoWL/model/model.py:38,54]:
+ * o = x - mean*mean_scale; y = weight*o/sqrt(mean(o^2)+eps) + bias, column-wise over all n rows;
+ * optional fused ReLU and `y = add_to + (...)` (the conv2s + conv2s_r sum, model.py:77).
+ * Column sums are accumulated in fp64 over a fixed block partition (reproducible). */
+int64_t lpg_graphnorm_bytes(int64_t n, int64_t d);
+int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const float* weight,
+                      const float* bias, const float* mean_scale, float eps, int relu,
+                      const float* add_to, float* y, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
+/* ---------------------------------------------------------------- TwoWL pair ops (K7-K9)
+ * embedding: out[i,:] = table[idx[i],:]                                  [model.py:71]
+ * pair_gather_mul: h[t,:] = x[pos[t,0],:] * x[pos[t,1],:], pos is [P,2]    [model.py:75]
+ * pair_readout: s[b] = w . (h[idx[2b]] * h[idx[2b+1]]) + b0               [model.py:78-83]
+ * flip_index: edge = (flip(e0), e1), edge_r = (e0, flip(e1)), flip(k) = k^1 [TwoWL/utils.py:71-78] */
+int lpg_embedding_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* idx,
+                      int64_t n, float* out, int32_t* err_flag, void* stream);
+int lpg_pair_gather_mul_f32(const float* x, int64_t n, int64_t d, const int64_t* pos, int64_t P,
+                            float* h, int32_t* err_flag, void* stream);
+int lpg_pair_readout_f32(const float* h, int64_t P, int64_t d, const int64_t* idx, int64_t B,
+                         const float* w, const float* b0, float* out, int32_t* err_flag,
+                         void* stream);
+int lpg_flip_index_i64(const int64_t* ei2, int64_t E2, int64_t* edge, int64_t* edge_r,
+                       void* stream);
+
+/* ---------------------------------------------------------------- 2-WL tuple graph (a3, a2)
+ * get_ei2(n_node, pos_edge, pred_edge) [TwoWL/utils.py:36-45]: tuple ids = columns of
+ * cat(pos_edge, pred_edge); for node i ascending, all (a, b) with pos_edge[1,a]==i, edge[0,b]==i,
+ * a-major b-minor.  Two calls: _count fills node_off[n+1] (exclusive scan of in_i*out_i) and the
+ * sorted id lists in `workspace`, and returns E2 through *e2_host (syncs); _fill writes [2,E2]. */
+int64_t lpg_get_ei2_bytes(int64_t n_node, int64_t E1, int64_t Ep);
+int lpg_get_ei2_count(const int64_t* pos_edge, int64_t E1, const int64_t* pred_edge, int64_t Ep,
+                      int64_t n_node, void* workspace, int64_t workspace_bytes,
+                      int64_t* e2_host, int32_t* err_flag, void* stream);
+int lpg_get_ei2_fill(const void* workspace, int64_t n_node, int64_t E1, int64_t Ep, int64_t E2,
+                     int64_t* ei2, void* stream);
+/* stable compaction of the columns of a [rows, E] int64 matrix where keep[e] != 0
+ * (the ei[:, mask] / blockei2 filters of sample_block, TwoWL/utils.py:48-50,61-68).
+ * mark_blocked: mask[idx[i]] = 1.  keep_from_blocked: keep[e] = !blocked[key[e]].
+ * Returns the kept count through *count_host (syncs). */
+int lpg_mark_i64(const int64_t* idx, int64_t n_idx, uint8_t* mask, int64_t n_mask,
+                 int32_t* err_flag, void* stream);
+int lpg_keep_from_blocked(const int64_t* key, int64_t E, const uint8_t* blocked, int64_t n_mask,
+                          int invert, uint8_t* keep, int32_t* err_flag, void* stream);
+int64_t lpg_compact_cols_bytes(int64_t E);
+int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8_t* keep,
+                         int64_t* out, void* workspace, int64_t workspace_bytes,
+                         int64_t* count_host, void* stream);
+
+/* ---------------------------------------------------------------- SEAL structure path (a10-a12)
+ * Batched 0/1-hop enclosing subgraphs + DRNL labels on the train graph given as a symmetric CSR
+ * (adj_rowptr[n+1], adj_col sorted ascending per row, self loops allowed)
+ * [SEAL/config/subgraph.py:105-141, SEAL/utils/utils.py:35-54].
+ * Per candidate pair b (pairs is [B,2]): nodes[b, 0:n_b] = [u, v, rest ascending]; capped[b] = 1
+ * when the reference's RNG-dependent 100-node truncation would trigger (then the caller supplies
+ * the node list: replay != 0 makes the kernel take nodes/n_nodes as INPUT).
+ * tags[b, i] = DRNL tag (raw, before the global compaction); adjacency is returned as a bit
+ * matrix adj_bits[b, i, w] (uint32 words, MAXN/32 words per row), target entries cleared. */
+#define LPG_SEAL_MAXN 128
+int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
+                       const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
+                       int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits,
+                       uint8_t* capped, int32_t* err_flag, void* stream);
+/* Block-diagonal CSR of A~ = A + I over a batch, D^-1 = 1/rowsum(A~), and
+ * X = [onehot(tag_map[tag], T) || emb[node]]  [SEAL/config/data.py:94-140].
+ * node_off[B+1] = exclusive scan of n_nodes (host-computed or torch.cumsum);
+ * edge capacity e_cap >= sum_b (nnz_b + n_b).  rowptr gets sum(n)+1 entries. */
+int lpg_seal_block_csr(const int32_t* n_nodes, const int64_t* node_off, const uint32_t* adj_bits,
+                       int64_t B, int64_t* rowptr, int32_t* col, float* val, float* d_inv,
+                       int64_t e_cap, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t lpg_seal_block_csr_bytes(int64_t total_nodes);
+int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_nodes, const int64_t* node_off,
+                          const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len,
+                          int64_t T, const float* emb, int64_t emb_dim, int64_t B, float* x,
+                          int64_t ldx, int32_t* err_flag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPG_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of liblpg_hip.so, generated from include/lpg_hip.h.
+
+The prototypes are parsed out of the header so the header stays the single source of truth for
+the C ABI (tests/test_abi.py checks that every declared symbol is exported).  There is no CPU
+fallback: if the shared library is missing the import of any op raises.
+"""
+import ctypes
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(ROOT, "include", "lpg_hip.h")
+LIB_PATH = os.path.join(_PKG, "csrc", "liblpg_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
+    "float": ctypes.c_float, "uint8_t": ctypes.c_uint8,
+}
+_PROTO = re.compile(r"^\s*(const\s+char\s*\*|int64_t|int)\s+(lpg_\w+)\s*\(([^)]*)\)\s*;", re.M | re.S)
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes], [argnames])} for every `lpg_*` prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for ret, name, args in _PROTO.findall(text):
+        ret = ret.replace(" ", "")
+        restype = ctypes.c_char_p if ret.startswith("constchar") else _CTYPES[ret]
+        argtypes, argnames = [], []
+        args = " ".join(args.split())
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                nm = re.findall(r"(\w+)$", a)[0]
+                ty = a[: -len(nm)].strip()
+                if "*" in ty:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPES[ty.replace("const ", "").strip()])
+                argnames.append(nm)
+        out[name] = (restype, argtypes, argnames)
+    return out
+
+
+class LpgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LpgError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` (or python link-prediction-gnn_amd/csrc/build.py). "
+            "This package has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes, _) in parse_header().items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.lpg_abi_version() != 1:
+        raise LpgError("liblpg_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().lpg_last_error()
+        raise LpgError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+    return rc

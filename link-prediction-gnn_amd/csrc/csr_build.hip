@@ -1,0 +1,259 @@
+// Once-per-graph structure work: COO -> dst-major CSR (with PyG's add_remaining_self_loops
+// folded in), gcn_norm on the CSR, and the SpMM plan (row-id stream + empty-row list).
+//
+// Reference anchors: edge_index is [2,E] int64, row 0 = source, row 1 = destination
+// (TwoWL/model/model.py:73,77 call GCNConv(x, edge_index); PyG flow source_to_target).
+// The stable order inside a destination row (original edge order, appended self loop last) is
+// the order PyG's scatter-add accumulates in on CPU.
+//
+// rocPRIM's radix sort is used for the one-time sort (library primitive, not on the timed path);
+// keys are made unique -- (row << 32 | edge id) -- so the result does not depend on the
+// library's stability guarantees.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "lpg_common.hpp"
+
+namespace {
+using namespace lpg;
+
+struct CooWs {
+  uint64_t* keys_in;
+  uint64_t* keys_out;
+  int32_t* loop_last;
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  int64_t total;
+};
+
+inline unsigned bits_for(int64_t n) {  // bits needed to represent values in [0, n]
+  unsigned b = 1;
+  while ((int64_t(1) << b) <= n) ++b;
+  return b;
+}
+
+size_t sort_tmp_bytes(int64_t M, unsigned end_bit) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_keys(nullptr, bytes, static_cast<uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr),
+                                 static_cast<size_t>(M), 0u, end_bit, hipStream_t(0), false);
+  return bytes;
+}
+
+CooWs carve(void* ws, int64_t E, int64_t N, int loops) {
+  CooWs w;
+  const int64_t M = E + (loops ? N : 0);
+  char* p = static_cast<char*>(ws);
+  w.keys_in = reinterpret_cast<uint64_t*>(p);
+  p += align_up(M * 8, 256);
+  w.keys_out = reinterpret_cast<uint64_t*>(p);
+  p += align_up(M * 8, 256);
+  w.loop_last = reinterpret_cast<int32_t*>(p);
+  p += align_up((N + 1) * 4, 256);
+  w.sort_tmp = p;
+  w.sort_tmp_bytes = sort_tmp_bytes(M > 0 ? M : 1, 32 + bits_for(N));
+  w.total = (p - static_cast<char*>(ws)) + static_cast<int64_t>(align_up(w.sort_tmp_bytes, 256));
+  return w;
+}
+
+__global__ __launch_bounds__(kBlock) void coo_keys_kernel(const int64_t* __restrict__ src,
+                                                          const int64_t* __restrict__ dst,
+                                                          const float* __restrict__ val, int64_t E, int64_t n_rows,
+                                                          int64_t n_cols, int loops, uint64_t* __restrict__ keys,
+                                                          int32_t* __restrict__ loop_last, int32_t* err_flag) {
+  const int64_t M = E + (loops ? n_rows : 0);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < M; e += stride) {
+    uint64_t row;
+    if (e < E) {
+      const int64_t s = src[e], t = dst[e];
+      if (s < 0 || s >= n_cols || t < 0 || t >= n_rows) {
+        flag_error(err_flag, LPG_F_INDEX_RANGE);
+        row = static_cast<uint64_t>(n_rows);  // dropped bucket
+      } else if (loops && s == t) {
+        row = static_cast<uint64_t>(n_rows);  // existing self loop: replaced by the appended one
+        if (val) atomicMax(&loop_last[s], static_cast<int32_t>(e));
+      } else {
+        row = static_cast<uint64_t>(t);
+      }
+    } else {
+      row = static_cast<uint64_t>(e - E);  // appended self loop of node e-E
+    }
+    keys[e] = (row << 32) | static_cast<uint64_t>(e);
+  }
+}
+
+// rowptr[r] = first sorted position whose row >= r, for r in [0, n_rows]; thread k owns the
+// rows in (row[k-1], row[k]].  No atomics, no scan.
+__global__ __launch_bounds__(kBlock) void rowptr_from_sorted_kernel(const uint64_t* __restrict__ keys, int64_t M,
+                                                                    int64_t n_rows, int64_t* __restrict__ rowptr) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; k <= M; k += stride) {
+    const int64_t a = (k == 0) ? -1 : static_cast<int64_t>(keys[k - 1] >> 32);
+    int64_t b = (k == M) ? n_rows : static_cast<int64_t>(keys[k] >> 32);
+    if (b > n_rows) b = n_rows;
+    for (int64_t r = a + 1; r <= b; ++r) rowptr[r] = k;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void coo_gather_kernel(const uint64_t* __restrict__ keys, int64_t M, int64_t E,
+                                                            const int64_t* __restrict__ src,
+                                                            const float* __restrict__ val,
+                                                            const int32_t* __restrict__ loop_last,
+                                                            int32_t* __restrict__ col_out, float* __restrict__ val_out,
+                                                            int32_t* __restrict__ perm_out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; k < M; k += stride) {
+    const int64_t e = static_cast<int64_t>(keys[k] & 0xffffffffull);
+    int32_t c;
+    float w = 1.f;
+    if (e < E) {
+      c = static_cast<int32_t>(src[e]);
+      if (val) w = val[e];
+    } else {
+      c = static_cast<int32_t>(e - E);
+      if (val) {
+        const int32_t last = loop_last[c];
+        if (last >= 0) w = val[last];
+      }
+    }
+    col_out[k] = c;
+    if (val_out) val_out[k] = w;
+    if (perm_out) perm_out[k] = static_cast<int32_t>(e);
+  }
+}
+
+// ---- gcn_norm: one wave per destination row; lanes stride the row, xor-shuffle tree reduce
+// (fixed association => reproducible).
+__global__ __launch_bounds__(kBlock) void row_weight_sum_kernel(const int64_t* __restrict__ rowptr,
+                                                                const float* __restrict__ val, int64_t N,
+                                                                float* __restrict__ dinv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  for (int64_t r = wave; r < N; r += nwaves) {
+    const int64_t b = rowptr[r], e = rowptr[r + 1];
+    float s = 0.f;
+    for (int64_t k = b + lane; k < e; k += 64) s += val ? val[k] : 1.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+      float di = 1.0f / sqrtf(s);      // deg^-1/2; deg == 0 -> inf -> 0 (masked_fill in gcn_norm)
+      if (isinf(di)) di = 0.f;
+      dinv[r] = di;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gcn_scale_kernel(const int64_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, float* __restrict__ val,
+                                                           const float* __restrict__ dinv, int64_t N) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  for (int64_t r = wave; r < N; r += nwaves) {
+    const int64_t b = rowptr[r], e = rowptr[r + 1];
+    const float dr = dinv[r];
+    for (int64_t k = b + lane; k < e; k += 64) val[k] = (dinv[col[k]] * val[k]) * dr;
+  }
+}
+
+// ---- plan: per-edge row ids + list of empty rows (+ column range check)
+__global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col, int64_t N, int64_t n_cols,
+                                                      int64_t e_cap, int32_t* __restrict__ n_empty,
+                                                      int32_t* __restrict__ rowid, int32_t* __restrict__ empty_rows,
+                                                      int32_t* err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  for (int64_t r = wave; r < N; r += nwaves) {
+    int64_t b = rowptr[r], e = rowptr[r + 1];
+    if (b < 0 || e < b || e > e_cap) {  // malformed rowptr: never index with it
+      if (lane == 0) flag_error(err_flag, LPG_F_INDEX_RANGE);
+      continue;
+    }
+    if (e == b) {
+      if (lane == 0) empty_rows[atomicAdd(n_empty, 1)] = static_cast<int32_t>(r);
+      continue;
+    }
+    for (int64_t k = b + lane; k < e; k += 64) {
+      rowid[k] = static_cast<int32_t>(r);
+      const int32_t c = col[k];
+      if (c < 0 || c >= n_cols) flag_error(err_flag, LPG_F_INDEX_RANGE);
+    }
+  }
+}
+}  // namespace
+
+LPG_EXPORT int64_t lpg_coo_to_csr_bytes(int64_t E, int64_t N, int gcn_self_loops) {
+  if (E < 0 || N < 0) return LPG_E_INVALID;
+  return carve(nullptr, E, N, gcn_self_loops).total;
+}
+
+LPG_EXPORT int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const float* val, int64_t E, int64_t n_rows,
+                              int64_t n_cols, int gcn_self_loops, int64_t* rowptr, int32_t* col_out, float* val_out,
+                              int32_t* perm_out, void* workspace, int64_t workspace_bytes, int32_t* err_flag,
+                              void* stream) {
+  LPG_REQUIRE(E >= 0 && n_rows >= 0 && n_cols >= 0, "coo_to_csr: negative size");
+  LPG_REQUIRE(!gcn_self_loops || n_rows == n_cols, "coo_to_csr: self loops need a square matrix");
+  const int64_t M = E + (gcn_self_loops ? n_rows : 0);
+  LPG_REQUIRE(M < (int64_t(1) << 31), "coo_to_csr: more than 2^31-1 edges");
+  LPG_REQUIRE(rowptr && (M == 0 || col_out) && (E == 0 || (src && dst)), "coo_to_csr: null pointer");
+  LPG_REQUIRE(!val || val_out, "coo_to_csr: val given without val_out");
+  CooWs w = carve(workspace, E, n_rows, gcn_self_loops);
+  if (workspace_bytes < w.total || (!workspace && w.total > 0)) {
+    set_error("coo_to_csr: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)w.total);
+    return LPG_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  if (gcn_self_loops && val) LPG_HIP(hipMemsetAsync(w.loop_last, 0xff, static_cast<size_t>(n_rows + 1) * 4, st));
+  if (M > 0) {
+    hipLaunchKernelGGL(coo_keys_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, src, dst, val, E, n_rows, n_cols,
+                       gcn_self_loops, w.keys_in, w.loop_last, err_flag);
+    size_t tmp = w.sort_tmp_bytes;
+    LPG_HIP(rocprim::radix_sort_keys(w.sort_tmp, tmp, w.keys_in, w.keys_out, static_cast<size_t>(M), 0u,
+                                     32 + bits_for(n_rows), st, false));
+  }
+  hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(grid_for(M + 1)), dim3(kBlock), 0, st, w.keys_out, M, n_rows,
+                     rowptr);
+  if (M > 0)
+    hipLaunchKernelGGL(coo_gather_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, w.keys_out, M, E, src, val,
+                       w.loop_last, col_out, val_out, perm_out);
+  return check_launch("coo_to_csr");
+}
+
+LPG_EXPORT int lpg_gcn_norm_csr(const int64_t* rowptr, const int32_t* col, float* val, float* dinv, int64_t N,
+                                void* stream) {
+  LPG_REQUIRE(N >= 0 && rowptr && val && dinv && col, "gcn_norm_csr: null pointer");
+  if (N == 0) return LPG_OK;
+  hipStream_t st = as_stream(stream);
+  const int grid = grid_for(N * 64);
+  hipLaunchKernelGGL(row_weight_sum_kernel, dim3(grid), dim3(kBlock), 0, st, rowptr, val, N, dinv);
+  hipLaunchKernelGGL(gcn_scale_kernel, dim3(grid), dim3(kBlock), 0, st, rowptr, col, val, dinv, N);
+  return check_launch("gcn_norm_csr");
+}
+
+LPG_EXPORT int64_t lpg_csr_plan_bytes(int64_t N, int64_t e_cap) {
+  if (N < 0 || e_cap < 0) return LPG_E_INVALID;
+  return 256 + align_up((e_cap + 1) * 4, 256) + align_up((N + 1) * 4, 256);
+}
+
+LPG_EXPORT int lpg_csr_plan_build(const int64_t* rowptr, const int32_t* col, int64_t N, int64_t n_cols,
+                                  int64_t e_cap, void* plan, int64_t plan_bytes, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(N >= 0 && e_cap >= 0 && rowptr && plan, "csr_plan_build: bad argument");
+  LPG_REQUIRE(e_cap < (int64_t(1) << 31) && N < (int64_t(1) << 31), "csr_plan_build: sizes exceed int32");
+  if (plan_bytes < lpg_csr_plan_bytes(N, e_cap)) {
+    set_error("csr_plan_build: plan buffer too small");
+    return LPG_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  char* p = static_cast<char*>(plan);
+  int32_t* n_empty = reinterpret_cast<int32_t*>(p);
+  int32_t* rowid = reinterpret_cast<int32_t*>(p + 256);
+  int32_t* empty_rows = reinterpret_cast<int32_t*>(p + 256 + align_up((e_cap + 1) * 4, 256));
+  LPG_HIP(hipMemsetAsync(p, 0, 256, st));
+  if (N > 0)
+    hipLaunchKernelGGL(plan_kernel, dim3(grid_for(N * 64)), dim3(kBlock), 0, st, rowptr, col, N, n_cols, e_cap,
+                       n_empty, rowid, empty_rows, err_flag);
+  return check_launch("csr_plan_build");
+}

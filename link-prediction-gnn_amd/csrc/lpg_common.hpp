@@ -1,0 +1,76 @@
+// Shared helpers for the gfx950 kernels of liblpg_hip.so (see include/lpg_hip.h for the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lpg_hip.h"
+
+#define LPG_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace lpg {
+
+constexpr int kWave = 64;   // CDNA4 wavefront
+constexpr int kBlock = 256; // 4 waves per workgroup, one per SIMD
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return LPG_E_LAUNCH;
+  }
+  return LPG_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t align_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// grid for a grid-stride elementwise kernel: enough workgroups to fill 256 CUs x 8, no more
+inline int grid_for(int64_t work_items, int block = kBlock, int64_t cap = 256 * 8) {
+  int64_t g = ceil_div(work_items, block);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return static_cast<int>(g);
+}
+
+#define LPG_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::lpg::set_error(__VA_ARGS__);      \
+      return LPG_E_INVALID;               \
+    }                                     \
+  } while (0)
+
+#define LPG_HIP(call)                                                        \
+  do {                                                                       \
+    hipError_t e_ = (call);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      ::lpg::set_error("%s failed: %s", #call, hipGetErrorString(e_));       \
+      return LPG_E_LAUNCH;                                                   \
+    }                                                                        \
+  } while (0)
+
+__device__ __forceinline__ void flag_error(int32_t* err_flag, int32_t bit) {
+  if (err_flag) atomicOr(err_flag, bit);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == LPG_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == LPG_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// bf16 <-> f32 (round to nearest even; plain casts keep NaN a NaN, see MI355X guide)
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(static_cast<uint32_t>(b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+}  // namespace lpg

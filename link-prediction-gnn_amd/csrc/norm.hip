@@ -1,0 +1,151 @@
+// GraphNorm over a single graph (K6).
+// torch_geometric.nn.GraphNorm.forward(x, batch=None) [3P, PyG 2.3.1]; reference call sites
+// TwoWL/model/model.py:38,54 (inside Seq, which passes only `out` to it => batch is None):
+//   mean = column mean;  o = x - mean * mean_scale;  y = weight * o / sqrt(mean(o^2) + eps) + bias
+//
+// Three launches: (1) per-block column sums of x and x^2 in fp64 over a FIXED row partition,
+// (2) one block folds the partials in block order and emits per-column shift/scale/bias,
+// (3) elementwise apply with optional fused ReLU and residual add (the conv2s + conv2s_r sum,
+// model.py:77).  fp64 sums make the one-pass variance safe: var = E[x^2] - mean^2*ms*(2-ms).
+#include "lpg_common.hpp"
+
+namespace {
+using namespace lpg;
+
+constexpr int kMaxPartBlocks = 512;
+
+__global__ __launch_bounds__(kBlock) void gn_partial_kernel(const float* __restrict__ x, int64_t n, int64_t d,
+                                                            int64_t rows_per_block, int dp_cols,
+                                                            double* __restrict__ part) {
+  __shared__ double sh[2][kBlock];
+  const int R = kBlock / dp_cols;  // rows handled per sweep
+  const int cl = threadIdx.x % dp_cols, rl = threadIdx.x / dp_cols;
+  const int64_t rb = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  int64_t re = rb + rows_per_block;
+  if (re > n) re = n;
+  for (int64_t cb = 0; cb < d; cb += dp_cols) {
+    const int64_t c = cb + cl;
+    double s = 0.0, s2 = 0.0;
+    if (c < d)
+      for (int64_t r = rb + rl; r < re; r += R) {
+        const double v = static_cast<double>(x[r * d + c]);
+        s += v;
+        s2 += v * v;
+      }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0 && c < d) {
+      for (int q = 1; q < R; ++q) {  // fixed order
+        s += sh[0][q * dp_cols + cl];
+        s2 += sh[1][q * dp_cols + cl];
+      }
+      part[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * d + c] = s;
+      part[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * d + c] = s2;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gn_finalize_kernel(const double* __restrict__ part, int nblocks, int64_t n,
+                                                             int64_t d, const float* __restrict__ weight,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ mean_scale, float eps,
+                                                             float* __restrict__ stats) {
+  for (int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; c < d;
+       c += static_cast<int64_t>(gridDim.x) * kBlock) {
+    double s = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+      s += part[(static_cast<int64_t>(b) * 2 + 0) * d + c];
+      s2 += part[(static_cast<int64_t>(b) * 2 + 1) * d + c];
+    }
+    const double mean = s / static_cast<double>(n);
+    const double ex2 = s2 / static_cast<double>(n);
+    const double ms = mean_scale ? static_cast<double>(mean_scale[c]) : 1.0;
+    double var = ex2 - mean * mean * ms * (2.0 - ms);
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + static_cast<double>(eps));
+    stats[c] = static_cast<float>(mean * ms);
+    stats[d + c] = static_cast<float>((weight ? static_cast<double>(weight[c]) : 1.0) * inv);
+    stats[2 * d + c] = bias ? bias[c] : 0.f;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restrict__ x, int64_t n, int64_t d,
+                                                          const float* __restrict__ stats, int relu,
+                                                          const float* __restrict__ add_to, float* __restrict__ y) {
+  const int64_t total = n * d / VEC;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t i = t * VEC;
+    const int64_t c = i % d;
+    float v[VEC], o[VEC];
+    if constexpr (VEC == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(x + i);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      v[0] = x[i];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float r = (v[k] - stats[c + k]) * stats[d + c + k] + stats[2 * d + c + k];
+      if (relu) r = r > 0.f ? r : 0.f;
+      o[k] = r;
+    }
+    if (add_to) {
+      if constexpr (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(add_to + i);
+        o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w;
+      } else {
+        o[0] += add_to[i];
+      }
+    }
+    if constexpr (VEC == 4)
+      *reinterpret_cast<float4*>(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+      y[i] = o[0];
+  }
+}
+
+inline int part_blocks(int64_t n, int64_t* rows_per_block) {
+  int64_t rpb = ceil_div(n, kMaxPartBlocks);
+  if (rpb < 64) rpb = 64;
+  *rows_per_block = rpb;
+  return static_cast<int>(ceil_div(n, rpb));
+}
+}  // namespace
+
+LPG_EXPORT int64_t lpg_graphnorm_bytes(int64_t n, int64_t d) {
+  if (n < 0 || d < 1) return LPG_E_INVALID;
+  return static_cast<int64_t>(kMaxPartBlocks) * 2 * d * 8 + lpg::align_up(3 * d * 4, 256) + 256;
+}
+
+LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const float* weight, const float* bias,
+                                 const float* mean_scale, float eps, int relu, const float* add_to, float* y,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  LPG_REQUIRE(n >= 0 && d >= 1, "graphnorm: bad sizes");
+  if (n == 0) return LPG_OK;
+  LPG_REQUIRE(x && y && workspace, "graphnorm: null pointer");
+  if (workspace_bytes < lpg_graphnorm_bytes(n, d)) {
+    set_error("graphnorm: workspace too small");
+    return LPG_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  double* part = static_cast<double*>(workspace);
+  float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + static_cast<int64_t>(kMaxPartBlocks) * 2 * d * 8);
+  int64_t rpb;
+  const int nb = part_blocks(n, &rpb);
+  int dp = 1;
+  while (dp < d && dp < kBlock) dp <<= 1;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nb), dim3(kBlock), 0, st, x, n, d, rpb, dp, part);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(static_cast<int>(ceil_div(d, kBlock))), dim3(kBlock), 0, st, part, nb, n,
+                     d, weight, bias, mean_scale, eps, stats);
+  const bool wide = d % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+                    (!add_to || reinterpret_cast<uintptr_t>(add_to) % 16 == 0);
+  if (wide)
+    hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(grid_for(n * d / 4)), dim3(kBlock), 0, st, x, n, d, stats, relu, add_to, y);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(grid_for(n * d)), dim3(kBlock), 0, st, x, n, d, stats, relu, add_to, y);
+  return check_launch("graphnorm");
+}

@@ -1,0 +1,116 @@
+// scatter_add kernels (K1/K2) + the library's error plumbing.
+// Reference call site: TwoWL/utils.py:10 (degree = scatter_add(ones_like(ei[1]), ei[1], dim_size=N));
+// torch_scatter.scatter_add semantics: out[index[e], :] += src[e, :].
+#include <stdarg.h>
+
+#include "lpg_common.hpp"
+
+namespace lpg {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace lpg
+
+LPG_EXPORT const char* lpg_last_error(void) { return lpg::g_err; }
+LPG_EXPORT int lpg_abi_version(void) { return LPG_ABI_VERSION; }
+
+namespace {
+using namespace lpg;
+
+// In-degree histogram for small N: one LDS histogram per workgroup (ds_add_u32), flushed with
+// one 64-bit global atomic per non-zero bin.  Integer adds commute => bit-exact in any order.
+constexpr int kLdsBins = 16384;  // 64 KiB of the CU's 160 KiB LDS
+
+__global__ __launch_bounds__(kBlock) void degree_lds_kernel(const int64_t* __restrict__ index, int64_t E,
+                                                            unsigned long long* __restrict__ out, int64_t N,
+                                                            int32_t* err_flag) {
+  extern __shared__ uint32_t bins[];
+  for (int i = threadIdx.x; i < N; i += kBlock) bins[i] = 0;
+  __syncthreads();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < E; e += stride) {
+    const int64_t j = index[e];
+    if (j >= 0 && j < N)
+      atomicAdd(&bins[j], 1u);
+    else
+      flag_error(err_flag, LPG_F_INDEX_RANGE);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += kBlock) {
+    const uint32_t c = bins[i];
+    if (c) atomicAdd(&out[i], static_cast<unsigned long long>(c));
+  }
+}
+
+// General integer scatter-add: lanes walk the flattened [E, d] source so one wave touches
+// contiguous bytes of a destination row.
+__global__ __launch_bounds__(kBlock) void scatter_add_i64_kernel(const int64_t* __restrict__ src,
+                                                                 const int64_t* __restrict__ index, int64_t E,
+                                                                 int64_t d, unsigned long long* __restrict__ out,
+                                                                 int64_t N, int32_t* err_flag) {
+  const int64_t total = E * d;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t e = t / d, c = t - e * d;
+    const int64_t j = index[e];
+    if (j >= 0 && j < N) {
+      const int64_t v = src ? src[t] : 1;
+      atomicAdd(&out[j * d + c], static_cast<unsigned long long>(v));
+    } else {
+      flag_error(err_flag, LPG_F_INDEX_RANGE);
+    }
+  }
+}
+
+// Float scatter-add: global_atomic_add_f32, one dword per lane, a wave covers 256 contiguous
+// bytes of a destination row whenever d >= 64 (the shape the memory-side atomic unit runs at
+// full rate for; MI355X guide, "Global float atomics").
+__global__ __launch_bounds__(kBlock) void scatter_add_f32_kernel(const float* __restrict__ src,
+                                                                 const int64_t* __restrict__ index, int64_t E,
+                                                                 int64_t d, float* __restrict__ out, int64_t N,
+                                                                 int32_t* err_flag) {
+  const int64_t total = E * d;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t e = t / d, c = t - e * d;
+    const int64_t j = index[e];
+    if (j >= 0 && j < N)
+      unsafeAtomicAdd(&out[j * d + c], src[t]);
+    else
+      flag_error(err_flag, LPG_F_INDEX_RANGE);
+  }
+}
+}  // namespace
+
+LPG_EXPORT int lpg_scatter_add_i64(const int64_t* src, const int64_t* index, int64_t E, int64_t d, int64_t* out,
+                                   int64_t N, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(E >= 0 && N >= 0 && d >= 1, "scatter_add_i64: bad sizes E=%lld N=%lld d=%lld", (long long)E,
+              (long long)N, (long long)d);
+  if (E == 0) return LPG_OK;
+  LPG_REQUIRE(index && out, "scatter_add_i64: null pointer");
+  hipStream_t st = as_stream(stream);
+  auto* o = reinterpret_cast<unsigned long long*>(out);
+  if (!src && d == 1 && N <= kLdsBins) {
+    const int grid = grid_for(E, kBlock, 256 * 2);
+    hipLaunchKernelGGL(degree_lds_kernel, dim3(grid), dim3(kBlock), static_cast<size_t>(N) * 4, st, index, E, o, N,
+                       err_flag);
+  } else {
+    hipLaunchKernelGGL(scatter_add_i64_kernel, dim3(grid_for(E * d)), dim3(kBlock), 0, st, src, index, E, d, o, N,
+                       err_flag);
+  }
+  return check_launch("scatter_add_i64");
+}
+
+LPG_EXPORT int lpg_scatter_add_f32(const float* src, const int64_t* index, int64_t E, int64_t d, float* out,
+                                   int64_t N, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(E >= 0 && N >= 0 && d >= 1, "scatter_add_f32: bad sizes");
+  if (E == 0) return LPG_OK;
+  LPG_REQUIRE(src && index && out, "scatter_add_f32: null pointer");
+  hipLaunchKernelGGL(scatter_add_f32_kernel, dim3(grid_for(E * d)), dim3(kBlock), 0, as_stream(stream), src, index,
+                     E, d, out, N, err_flag);
+  return check_launch("scatter_add_f32");
+}

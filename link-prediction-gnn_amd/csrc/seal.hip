@@ -1,0 +1,374 @@
+// SEAL structure path on the device (a10, a11, a12): batched 0/1-hop enclosing subgraphs, DRNL
+// node labels, block-diagonal A~ = A + I with D^-1, and X = [onehot(tag) || emb].
+//
+// Reference: SEAL/config/subgraph.py:105-141 (extract_subgraph), SEAL/utils/utils.py:35-54
+// (node_labeling), SEAL/config/data.py:94-140 (create_input_for_gnn_fly).  The reference walks
+// candidates one at a time with networkx (2(n-2) BFS calls per subgraph) and feeds dense [n,n]
+// float matrices; here one workgroup owns one candidate pair, the subgraph lives in LDS as a
+// 128x128 bit matrix, and both BFS runs are level-synchronous bitset sweeps.
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+#include "lpg_common.hpp"
+
+namespace {
+using namespace lpg;
+
+constexpr int MAXN = LPG_SEAL_MAXN;  // 128 >= the reference's max_neighbors = 100
+constexpr int WORDS = MAXN / 32;
+constexpr int kSealBlock = 128;      // thread i <-> subgraph vertex i
+
+__device__ __forceinline__ bool row_has(const int32_t* __restrict__ row, int len, int32_t key) {
+  int lo = 0, hi = len;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t v = row[mid];
+    if (v < key) lo = mid + 1; else hi = mid;
+  }
+  return lo < len && row[lo] == key;
+}
+
+__device__ void bfs_bits(const uint32_t (*adj)[WORDS], int n, int src, int* dist, uint32_t* vis, uint32_t* fr,
+                         uint32_t* nx) {
+  const int t = threadIdx.x;
+  if (t < MAXN) dist[t] = -1;
+  if (t < WORDS) { vis[t] = 0; fr[t] = 0; nx[t] = 0; }
+  __syncthreads();
+  if (t == 0) {
+    dist[src] = 0;
+    vis[src >> 5] = 1u << (src & 31);
+    fr[src >> 5] = 1u << (src & 31);
+  }
+  __syncthreads();
+  for (int level = 1; level <= n; ++level) {      // at most n-1 productive levels
+    if (t < n && ((fr[t >> 5] >> (t & 31)) & 1u)) {
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) {
+        const uint32_t m = adj[t][w];
+        if (m) atomicOr(&nx[w], m);
+      }
+    }
+    __syncthreads();
+    bool any = false;
+    uint32_t fresh[WORDS];
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) {
+      fresh[w] = nx[w] & ~vis[w];
+      any |= fresh[w] != 0;
+    }
+    if (t < n && ((fresh[t >> 5] >> (t & 31)) & 1u)) dist[t] = level;
+    __syncthreads();
+    if (t < WORDS) { vis[t] |= fresh[t]; fr[t] = fresh[t]; nx[t] = 0; }
+    __syncthreads();
+    if (!any) break;                               // uniform: every thread computed the same `any`
+  }
+}
+
+__global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_graph, const int64_t* __restrict__ pairs,
+    int64_t B, int hop, int max_nb, int replay, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
+    int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag) {
+  __shared__ int32_t cand[2 * MAXN];
+  __shared__ int32_t nodes[MAXN];
+  __shared__ uint32_t adj[MAXN][WORDS];
+  __shared__ int dist0[MAXN], dist1[MAXN];
+  __shared__ uint32_t vis[WORDS], fr[WORDS], nx[WORDS];
+  __shared__ int s_n, s_capped;
+  const int t = threadIdx.x;
+
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    const int64_t u64 = pairs[2 * b], v64 = pairs[2 * b + 1];
+    const bool bad = u64 < 0 || u64 >= n_graph || v64 < 0 || v64 >= n_graph;
+    if (bad) {                                       // block-uniform
+      if (t == 0) { flag_error(err_flag, LPG_F_INDEX_RANGE); n_out[b] = 0; capped_out[b] = 0; }
+      continue;
+    }
+    const int32_t u = static_cast<int32_t>(u64), v = static_cast<int32_t>(v64);
+    if (t == 0) { s_n = 0; s_capped = 0; }
+    for (int i = t; i < MAXN; i += kSealBlock) {
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) adj[i][w] = 0;
+    }
+    __syncthreads();
+
+    if (replay) {
+      int n = n_out[b];
+      if (n < 2 || n > MAXN) n = 0;
+      for (int i = t; i < n; i += kSealBlock) {
+        int32_t x = nodes_out[b * MAXN + i];
+        if (x < 0 || x >= n_graph) { flag_error(err_flag, LPG_F_INDEX_RANGE); x = u; }
+        nodes[i] = x;
+      }
+      if (t == 0) s_n = n;
+      __syncthreads();
+    } else {
+      // ---- node set: {u, v} U N(u) U N(v), the reference's cap rule (subgraph.py:123-130)
+      if (t == 0) {
+        // The reference visits the two targets in a SHUFFLED order (:122); the truncation branch
+        // fires when len(sub) + len(neighbours) >= max_neighbors at either visit.  `capped` is
+        // set when it would fire in either order, so the uncapped result is order-free.
+        const int size0 = (u == v) ? 1 : 2;
+        int cap = 0;
+        if (hop >= 1) {
+          const int64_t bu = rowptr[u], du = rowptr[u + 1] - bu;
+          const int64_t bv = rowptr[v], dv = rowptr[v + 1] - bv;
+          if (size0 + du >= max_nb || size0 + dv >= max_nb) {
+            cap = 1;
+          } else {
+            int eu = 0, ev = 0;   // |N(x) \ {u, v}|
+            for (int64_t k = 0; k < du; ++k) { const int32_t x = col[bu + k]; eu += (x != u && x != v); }
+            for (int64_t k = 0; k < dv; ++k) { const int32_t x = col[bv + k]; ev += (x != u && x != v); }
+            if (size0 + eu + dv >= max_nb || size0 + ev + du >= max_nb) cap = 1;
+          }
+        }
+        s_capped = cap;
+      }
+      __syncthreads();
+      if (s_capped) {                               // RNG-dependent in the reference: caller replays
+        if (t == 0) { n_out[b] = 0; capped_out[b] = 1; }
+        continue;
+      }
+      int n_c = 0;
+      if (hop >= 1) {
+        const int64_t bu = rowptr[u], bv = rowptr[v];
+        const int du = static_cast<int>(rowptr[u + 1] - bu), dv = static_cast<int>(rowptr[v + 1] - bv);
+        // candidates: N(u) \ {u,v}, then N(v) \ ({u,v} U N(u)); marked -1 when dropped
+        for (int i = t; i < du; i += kSealBlock) {
+          const int32_t x = col[bu + i];
+          cand[i] = (x == u || x == v) ? -1 : x;
+        }
+        if (u != v)
+          for (int i = t; i < dv; i += kSealBlock) {
+            const int32_t x = col[bv + i];
+            cand[du + i] = (x == u || x == v || row_has(col + bu, du, x)) ? -1 : x;
+          }
+        n_c = du + (u != v ? dv : 0);
+      }
+      __syncthreads();
+      // rank sort (keys unique): position = number of smaller kept keys
+      for (int i = t; i < n_c; i += kSealBlock) {
+        const int32_t x = cand[i];
+        if (x >= 0) {
+          int rank = 0;
+          for (int j = 0; j < n_c; ++j) { const int32_t y = cand[j]; rank += (y >= 0 && y < x); }
+          nodes[2 + rank] = x;
+          atomicAdd(&s_n, 1);
+        }
+      }
+      if (t == 0) { nodes[0] = u; nodes[1] = v; }
+      __syncthreads();
+      if (t == 0) s_n += 2;
+      __syncthreads();
+    }
+    const int n = s_n;
+    if (n == 0) {
+      if (t == 0) { n_out[b] = 0; capped_out[b] = replay ? 0 : 1; }
+      continue;
+    }
+
+    // ---- induced adjacency: bit (i, j) = A[nodes[i], nodes[j]], target entries cleared (:136-137)
+    for (int p = t; p < n * n; p += kSealBlock) {
+      const int i = p / n, j = p - i * n;
+      const int32_t a = nodes[i];
+      const int64_t ba = rowptr[a];
+      const int da = static_cast<int>(rowptr[a + 1] - ba);
+      if (row_has(col + ba, da, nodes[j]) && !((i == 0 && j == 1) || (i == 1 && j == 0)))
+        atomicOr(&adj[i][j >> 5], 1u << (j & 31));
+    }
+    __syncthreads();
+
+    // ---- DRNL (utils.py:35-54): two BFS sweeps on the bit matrix
+    bfs_bits(adj, n, 0, dist0, vis, fr, nx);
+    __syncthreads();
+    bfs_bits(adj, n, 1, dist1, vis, fr, nx);
+    __syncthreads();
+    if (t < MAXN) {
+      int tag = -1, nd = -1;
+      if (t < n) {
+        nd = nodes[t];
+        if (t < 2) {
+          tag = 1;
+        } else {
+          const int dx = dist0[t], dy = dist1[t];
+          if (dx < 0 || dy < 0) {
+            tag = 0;
+          } else {
+            const int d = dx + dy, dv2 = d >> 1, md = d & 1;
+            tag = 1 + (dx < dy ? dx : dy) + dv2 * (dv2 + md - 1);
+          }
+        }
+      }
+      tags_out[b * MAXN + t] = tag;
+      if (!replay) nodes_out[b * MAXN + t] = nd;
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) adj_out[(b * MAXN + t) * WORDS + w] = t < n ? adj[t][w] : 0u;
+    }
+    if (t == 0) { n_out[b] = n; capped_out[b] = 0; }
+  }
+}
+
+// ---- block-diagonal CSR of A~ = A + I --------------------------------------------------------
+// global vertex g = node_off[b] + i.  Row length = popcount(adj row) + (diagonal clear ? 1 : 0);
+// the diagonal value is A[i][i] + 1 (uint8 add at SEAL/config/data.py:94-95), rowsum = popcount + 1.
+__device__ __forceinline__ int64_t graph_of(const int64_t* __restrict__ node_off, int64_t B, int64_t g) {
+  int64_t lo = 0, hi = B;   // largest b with node_off[b] <= g
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (node_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void seal_rowlen_kernel(const int64_t* __restrict__ node_off,
+                                                             const uint32_t* __restrict__ adj_bits, int64_t B,
+                                                             int64_t total, int64_t* __restrict__ len,
+                                                             float* __restrict__ d_inv) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; g <= total; g += stride) {
+    if (g == total) { len[g] = 0; continue; }
+    const int64_t b = graph_of(node_off, B, g);
+    const int i = static_cast<int>(g - node_off[b]);
+    const uint32_t* row = adj_bits + (b * MAXN + i) * WORDS;
+    int pc = 0;
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) pc += __popc(row[w]);
+    const bool diag = (row[i >> 5] >> (i & 31)) & 1u;
+    len[g] = pc + (diag ? 0 : 1);
+    d_inv[g] = static_cast<float>(1.0 / static_cast<double>(pc + 1));
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void seal_fill_kernel(const int64_t* __restrict__ node_off,
+                                                           const uint32_t* __restrict__ adj_bits, int64_t B,
+                                                           int64_t total, const int64_t* __restrict__ rowptr,
+                                                           int32_t* __restrict__ col, float* __restrict__ val,
+                                                           int64_t e_cap) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; g < total; g += stride) {
+    const int64_t b = graph_of(node_off, B, g);
+    const int64_t base = node_off[b];
+    const int i = static_cast<int>(g - base);
+    const uint32_t* row = adj_bits + (b * MAXN + i) * WORDS;
+    int64_t k = rowptr[g];
+    bool diag_done = false;
+    for (int w = 0; w < WORDS; ++w) {
+      uint32_t m = row[w];
+      while (m) {
+        const int j = (w << 5) + __ffs(m) - 1;
+        m &= m - 1;
+        if (!diag_done && j > i) {                  // diagonal not set in A: insert the +I entry in order
+          if (k < e_cap) { col[k] = static_cast<int32_t>(base + i); val[k] = 1.f; }
+          ++k;
+          diag_done = true;
+        }
+        if (k < e_cap) { col[k] = static_cast<int32_t>(base + j); val[k] = (j == i) ? 2.f : 1.f; }
+        if (j == i) diag_done = true;
+        ++k;
+      }
+    }
+    if (!diag_done) {
+      if (k < e_cap) { col[k] = static_cast<int32_t>(base + i); val[k] = 1.f; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void seal_features_kernel(const int32_t* __restrict__ nodes,
+                                                               const int64_t* __restrict__ node_off,
+                                                               const int32_t* __restrict__ tags,
+                                                               const int32_t* __restrict__ tag_map, int64_t tag_map_len,
+                                                               int64_t T, const float* __restrict__ emb, int64_t emb_dim,
+                                                               int64_t B, int64_t total, float* __restrict__ x,
+                                                               int64_t ldx, int32_t* err_flag) {
+  const int64_t width = T + emb_dim;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total * width; q += stride) {
+    const int64_t g = q / width, c = q - g * width;
+    const int64_t b = graph_of(node_off, B, g);
+    const int i = static_cast<int>(g - node_off[b]);
+    float v;
+    if (c < T) {
+      int32_t tg = tags[b * MAXN + i];
+      if (tag_map) {
+        if (tg >= 0 && tg < tag_map_len) tg = tag_map[tg]; else { flag_error(err_flag, LPG_F_INDEX_RANGE); tg = -1; }
+      }
+      v = (tg == c) ? 1.f : 0.f;
+    } else {
+      v = emb[static_cast<int64_t>(nodes[b * MAXN + i]) * emb_dim + (c - T)];
+    }
+    x[g * ldx + c] = v;
+  }
+}
+}  // namespace
+
+LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
+                                  const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
+                                  int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits, uint8_t* capped,
+                                  int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(B >= 0 && n_graph_nodes >= 0, "seal_subgraphs: bad sizes");
+  LPG_REQUIRE(hop == 0 || hop == 1, "seal_subgraphs: hop must be 0 or 1 (the reference itself fails for hop >= 2)");
+  LPG_REQUIRE(max_neighbors >= 2 && max_neighbors <= MAXN, "seal_subgraphs: max_neighbors must be in [2, %d]", MAXN);
+  if (B == 0) return LPG_OK;
+  LPG_REQUIRE(adj_rowptr && pairs && nodes && n_nodes && tags && adj_bits && capped, "seal_subgraphs: null pointer");
+  const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
+  hipLaunchKernelGGL(seal_subgraph_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), adj_rowptr, adj_col,
+                     n_graph_nodes, pairs, B, hop, max_neighbors, replay, nodes, n_nodes, tags, adj_bits, capped, err_flag);
+  return check_launch("seal_subgraphs");
+}
+
+LPG_EXPORT int64_t lpg_seal_block_csr_bytes(int64_t total_nodes) {
+  if (total_nodes < 0) return LPG_E_INVALID;
+  size_t s = 0;
+  (void)rocprim::exclusive_scan(nullptr, s, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), int64_t(0),
+                                static_cast<size_t>(total_nodes + 1), rocprim::plus<int64_t>(), hipStream_t(0), false);
+  return lpg::align_up((total_nodes + 2) * 8, 256) + lpg::align_up(static_cast<int64_t>(s), 256) + 256;
+}
+
+// Phase 1 (col == NULL): rowptr[total+1] and d_inv[total].  Phase 2 (col != NULL): fill col/val.
+LPG_EXPORT int lpg_seal_block_csr(const int32_t* n_nodes, const int64_t* node_off, const uint32_t* adj_bits, int64_t B,
+                                  int64_t* rowptr, int32_t* col, float* val, float* d_inv, int64_t e_cap,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  LPG_REQUIRE(B >= 0 && node_off && rowptr, "seal_block_csr: bad argument");
+  (void)n_nodes;
+  hipStream_t st = as_stream(stream);
+  int64_t total = 0;
+  LPG_HIP(hipMemcpyAsync(&total, node_off + B, 8, hipMemcpyDeviceToHost, st));
+  LPG_HIP(hipStreamSynchronize(st));
+  LPG_REQUIRE(total >= 0 && total < (int64_t(1) << 31), "seal_block_csr: bad node_off");
+  if (!col) {
+    LPG_REQUIRE(d_inv && adj_bits && workspace, "seal_block_csr: null pointer");
+    if (workspace_bytes < lpg_seal_block_csr_bytes(total)) {
+      set_error("seal_block_csr: workspace too small");
+      return LPG_E_WORKSPACE;
+    }
+    int64_t* len = static_cast<int64_t*>(workspace);
+    void* tmp = static_cast<char*>(workspace) + align_up((total + 2) * 8, 256);
+    size_t tb = static_cast<size_t>(workspace_bytes - align_up((total + 2) * 8, 256));
+    hipLaunchKernelGGL(seal_rowlen_kernel, dim3(grid_for(total + 1)), dim3(kBlock), 0, st, node_off, adj_bits, B, total, len, d_inv);
+    LPG_HIP(rocprim::exclusive_scan(tmp, tb, len, rowptr, int64_t(0), static_cast<size_t>(total + 1),
+                                    rocprim::plus<int64_t>(), st, false));
+  } else {
+    LPG_REQUIRE(val && adj_bits, "seal_block_csr: null pointer");
+    if (total > 0)
+      hipLaunchKernelGGL(seal_fill_kernel, dim3(grid_for(total)), dim3(kBlock), 0, st, node_off, adj_bits, B, total, rowptr, col, val, e_cap);
+  }
+  return check_launch("seal_block_csr");
+}
+
+LPG_EXPORT int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_nodes, const int64_t* node_off,
+                                     const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len, int64_t T,
+                                     const float* emb, int64_t emb_dim, int64_t B, float* x, int64_t ldx,
+                                     int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(B >= 0 && T >= 0 && emb_dim >= 0 && ldx >= T + emb_dim, "seal_features: bad sizes");
+  (void)n_nodes;
+  if (B == 0 || T + emb_dim == 0) return LPG_OK;
+  LPG_REQUIRE(nodes && node_off && tags && x && (emb_dim == 0 || emb), "seal_features: null pointer");
+  hipStream_t st = as_stream(stream);
+  int64_t total = 0;
+  LPG_HIP(hipMemcpyAsync(&total, node_off + B, 8, hipMemcpyDeviceToHost, st));
+  LPG_HIP(hipStreamSynchronize(st));
+  if (total > 0)
+    hipLaunchKernelGGL(seal_features_kernel, dim3(grid_for(total * (T + emb_dim))), dim3(kBlock), 0, st, nodes, node_off, tags,
+                       tag_map, tag_map_len, T, emb, emb_dim, B, total, x, ldx, err_flag);
+  return check_launch("seal_features");
+}

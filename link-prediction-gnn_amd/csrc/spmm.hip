@@ -1,0 +1,358 @@
+// CSR SpMM  Y = act(row_scale * (A @ X) + bias)  -- the hot kernel (K4 / K10).
+//
+// Reference anchors: the propagate step of GCNConv (TwoWL/model/model.py:73,77, [3P] PyG:
+// out[dst] += w_e * h[src]) and SEAL's tanh(D^-1 (A~ (X W))) (SEAL/model/gnn.py:47-60).
+//
+// Design (gfx950, 64-lane waves, HBM-bound gather):
+//  * The nnz array is cut into fixed chunks of kChunk edges.  A *group* of G lanes owns one chunk;
+//    the G lanes span the feature row with one 16-byte load each (fp32: G = d/4, bf16: G = d/8),
+//    so a wave gathers 64/G source rows per load instruction and every load is a full 16 B/lane.
+//  * Column indices, edge weights and the per-edge row id are read coalesced (one per lane per
+//    G edges) and broadcast inside the group with ds_bpermute; U = 8 independent row gathers are
+//    issued back to back before the first accumulate, so each wave keeps 8 KiB in flight.
+//  * Work is balanced by EDGES, not rows: a 180 K-edge hub row is just 700 chunks.  A segment
+//    (run of edges of one row) that lies inside its chunk is reduced in registers and stored once;
+//    a segment cut by a chunk border is written to a carry slot and finished by the fix-up kernel,
+//    which adds the partials of that row in ascending chunk order.  No atomics anywhere, so the
+//    result is bitwise reproducible run to run.
+//  * Rows with no edges never appear in the edge stream; the plan lists them and a third tiny
+//    kernel writes act(bias) there.
+//  * The actual nnz is read from rowptr[N] on the device: launch geometry depends only on the
+//    capacity, so no host sync is needed between graph build and SpMM.
+#include "lpg_common.hpp"
+
+namespace {
+using namespace lpg;
+
+constexpr int kChunk = 256;  // edges per group chunk
+
+struct SpmmArgs {
+  const int64_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  const int32_t* rowid;
+  const int32_t* n_empty;
+  const int32_t* empty_rows;
+  const void* x;
+  void* y;
+  int64_t ldx, ldy, N, d;
+  const float* row_scale;
+  const float* bias;
+  int act;
+  float* carry;   // [2 * n_chunks_cap][dpad]
+  int64_t dpad;
+};
+
+// ---- 16-byte (or scalar) row pieces ---------------------------------------------------------
+// Raw = what one lane loads from a source row; it stays raw in registers while U gathers are in
+// flight (bf16: 4 VGPRs per piece instead of 8) and is widened to fp32 at the accumulate.
+template <typename T, int VEC>
+struct Piece;
+template <>
+struct Piece<float, 4> {
+  using Raw = float4;
+  static __device__ __forceinline__ Raw load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void widen(const Raw& t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct Piece<float, 1> {
+  using Raw = float;
+  static __device__ __forceinline__ Raw load(const float* p) { return *p; }
+  static __device__ __forceinline__ void widen(const Raw& t, float (&v)[1]) { v[0] = t; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+template <>
+struct Piece<uint16_t, 8> {
+  using Raw = uint4;
+  static __device__ __forceinline__ Raw load(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void widen(const Raw& t, float (&v)[8]) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = static_cast<uint32_t>(f32_to_bf16(v[2 * i])) | (static_cast<uint32_t>(f32_to_bf16(v[2 * i + 1])) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+template <>
+struct Piece<uint16_t, 1> {
+  using Raw = uint16_t;
+  static __device__ __forceinline__ Raw load(const uint16_t* p) { return *p; }
+  static __device__ __forceinline__ void widen(const Raw& t, float (&v)[1]) { v[0] = bf16_to_f32(t); }
+  static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[1]) { *p = f32_to_bf16(v[0]); }
+};
+
+template <int VEC>
+__device__ __forceinline__ void carry_store(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) *reinterpret_cast<float4*>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = v[i];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void carry_add(const float* p, float (&acc)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + i);
+      acc[i] += t.x; acc[i + 1] += t.y; acc[i + 2] += t.z; acc[i + 3] += t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += p[i];
+  }
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_out(const SpmmArgs& a, int64_t row, int64_t c0, const float (&acc)[VEC]) {
+  float o[VEC];
+  const float rs = a.row_scale ? a.row_scale[row] : 1.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float v = acc[i];
+    if (a.row_scale) v *= rs;
+    if (a.bias) v += a.bias[c0 + i];
+    o[i] = apply_act(v, a.act);
+  }
+  Piece<T, VEC>::store(static_cast<T*>(a.y) + row * a.ldy + c0, o);
+}
+
+// ---- main kernel -----------------------------------------------------------------------------
+template <typename T, int VEC, int G, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
+  constexpr int GPW = kWave / G;            // groups (chunks) per wave
+  constexpr int U = G < 8 ? G : 8;          // row gathers in flight per group step
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t E = a.rowptr[a.N];
+  if (wave * GPW * kChunk >= E) return;     // wave-uniform
+  const int64_t chunk = wave * GPW + lane / G;
+  const int64_t start = chunk * kChunk;
+  int64_t rem = E - start;
+  const int n_e = rem <= 0 ? 0 : (rem > kChunk ? kChunk : static_cast<int>(rem));
+
+  int64_t c0 = static_cast<int64_t>(blockIdx.y) * (G * VEC) + gl * VEC;
+  const bool lane_on = c0 < a.d;
+  if (!lane_on) c0 = 0;                     // keep the (ignored) loads in bounds
+  const T* xb = static_cast<const T*>(a.x) + c0;
+
+  bool open_left = false, open_right = false;
+  if (n_e > 0) {
+    open_left = start > 0 && a.rowid[start - 1] == a.rowid[start];
+    const int64_t last = start + n_e - 1;
+    open_right = last + 1 < E && a.rowid[last] == a.rowid[last + 1];
+  }
+  bool first_seg = true;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  float* carry0 = a.carry + (2 * chunk) * a.dpad + c0;
+
+#pragma unroll 1
+  for (int base = 0; base < kChunk; base += G) {
+    if (!__any(base < n_e)) break;
+    const bool in = base + gl < n_e;
+    const int64_t e = start + base + gl;
+    const int c = in ? a.col[e] : 0;
+    const int r = in ? a.rowid[e] : -1;
+    const int rn = (in && e + 1 < E) ? a.rowid[e + 1] : -2;
+    const int fl = (in && r != rn) ? 1 : 0;
+    float w = 0.f;
+    if constexpr (WEIGHTED) w = in ? a.val[e] : 0.f;
+
+#pragma unroll 1
+    for (int j0 = 0; j0 < G; j0 += U) {
+      typename Piece<T, VEC>::Raw raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cj = __shfl(c, j0 + u, G);
+        raw[u] = Piece<T, VEC>::load(xb + static_cast<int64_t>(cj) * a.ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = base + j0 + u < n_e;
+        const int fj = __shfl(fl, j0 + u, G);
+        const int rj = __shfl(r, j0 + u, G);
+        float v[VEC];
+        Piece<T, VEC>::widen(raw[u], v);
+        if constexpr (WEIGHTED) {
+          const float wj = __shfl(w, j0 + u, G);   // 0 for edges past the chunk end
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wj, ok ? v[i] : 0.f, acc[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += ok ? v[i] : 0.f;
+        }
+        if (fj) {                                   // a row ends at this edge
+          if (lane_on) {
+            if (first_seg && open_left)
+              carry_store<VEC>(carry0, acc);        // last piece of a row begun in an earlier chunk
+            else
+              store_out<T, VEC>(a, rj, c0, acc);
+          }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+          first_seg = false;
+        }
+      }
+    }
+  }
+  if (open_right && lane_on) carry_store<VEC>(carry0 + ((first_seg && open_left) ? 0 : a.dpad), acc);
+}
+
+// ---- fix-up: finish the rows that straddle chunk borders --------------------------------------
+template <typename T, int VEC, int G>
+__global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
+  constexpr int GPW = kWave / G;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t E = a.rowptr[a.N];
+  if (wave * GPW * kChunk >= E) return;
+  const int64_t chunk = wave * GPW + lane / G;
+  const int64_t start = chunk * kChunk;
+  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * (G * VEC) + gl * VEC;
+  if (start >= E || start == 0 || c0 >= a.d) return;
+  const int r0 = a.rowid[start];
+  if (a.rowid[start - 1] != r0) return;             // first segment starts here: nothing pending
+  const int64_t end = start + kChunk;
+  if (end < E && a.rowid[end] == r0) return;        // row continues: a later chunk finishes it
+  const int64_t first = a.rowptr[r0] / kChunk;      // chunk holding the row's first edge
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  carry_add<VEC>(a.carry + (2 * first + 1) * a.dpad + c0, acc);
+  const float* p = a.carry + c0;
+  int64_t c = first + 1;
+  for (; c + 4 <= chunk + 1; c += 4) {              // 4 partial rows in flight, added in order
+    float t[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) t[u][i] = 0.f;
+      carry_add<VEC>(p + 2 * (c + u) * a.dpad, t[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += t[u][i];
+  }
+  for (; c <= chunk; ++c) carry_add<VEC>(p + 2 * c * a.dpad, acc);
+  store_out<T, VEC>(a, r0, c0, acc);
+}
+
+// ---- rows without edges: act(bias) -------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spmm_empty_rows_kernel(const SpmmArgs a) {
+  const int64_t total = static_cast<int64_t>(*a.n_empty) * a.d;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t i = t / a.d, c = t - i * a.d;
+    const int64_t row = a.empty_rows[i];
+    float acc[1] = {0.f};
+    store_out<T, 1>(a, row, c, acc);
+  }
+}
+
+template <typename T, int VEC, int G>
+int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
+  constexpr int GPW = kWave / G;
+  const int64_t n_chunks = ceil_div(e_cap, kChunk);
+  const int64_t n_waves = ceil_div(n_chunks, GPW);
+  const int64_t n_blocks = ceil_div(n_waves, kBlock / kWave);
+  const int64_t tiles = ceil_div(a.d, G * VEC);
+  LPG_REQUIRE(n_blocks < (int64_t(1) << 31) && tiles < 65536, "csr_spmm: grid too large");
+  dim3 grid(static_cast<unsigned>(n_blocks), static_cast<unsigned>(tiles));
+  if (a.val)
+    hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, true>), grid, dim3(kBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, false>), grid, dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((spmm_fixup_kernel<T, VEC, G>), grid, dim3(kBlock), 0, st, a);
+  return LPG_OK;
+}
+
+template <typename T, int VEC>
+int launch_vec(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
+  const int64_t lanes = ceil_div(a.d, VEC);
+  if (lanes <= 1) return launch_g<T, VEC, 1>(a, e_cap, st);
+  if (lanes <= 2) return launch_g<T, VEC, 2>(a, e_cap, st);
+  if (lanes <= 4) return launch_g<T, VEC, 4>(a, e_cap, st);
+  if (lanes <= 8) return launch_g<T, VEC, 8>(a, e_cap, st);
+  if (lanes <= 16) return launch_g<T, VEC, 16>(a, e_cap, st);
+  if (lanes <= 32) return launch_g<T, VEC, 32>(a, e_cap, st);
+  return launch_g<T, VEC, 64>(a, e_cap, st);
+}
+
+template <typename T, int WIDE>
+int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val, const T* x,
+               int64_t ldx, T* y, int64_t ldy, int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
+               const float* bias, int act, void* workspace, int64_t workspace_bytes, void* stream) {
+  LPG_REQUIRE(N >= 0 && e_cap >= 0 && d >= 1, "csr_spmm: bad sizes N=%lld e_cap=%lld d=%lld", (long long)N,
+              (long long)e_cap, (long long)d);
+  if (N == 0) return LPG_OK;
+  LPG_REQUIRE(plan && rowptr && x && y && (e_cap == 0 || col), "csr_spmm: null pointer");
+  LPG_REQUIRE(ldx >= d && ldy >= d, "csr_spmm: leading dimension smaller than d");
+  LPG_REQUIRE(act >= LPG_ACT_NONE && act <= LPG_ACT_TANH, "csr_spmm: unknown activation %d", act);
+  const int64_t need = lpg_csr_spmm_bytes(e_cap, d);
+  if (workspace_bytes < need || (!workspace && need > 0)) {
+    set_error("csr_spmm: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    return LPG_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const char* p = static_cast<const char*>(plan);
+  SpmmArgs a;
+  a.rowptr = rowptr; a.col = col; a.val = val;
+  a.n_empty = reinterpret_cast<const int32_t*>(p);
+  a.rowid = reinterpret_cast<const int32_t*>(p + 256);
+  a.empty_rows = reinterpret_cast<const int32_t*>(p + 256 + align_up((e_cap + 1) * 4, 256));
+  a.x = x; a.y = y; a.ldx = ldx; a.ldy = ldy; a.N = N; a.d = d;
+  a.row_scale = row_scale; a.bias = bias; a.act = act;
+  a.carry = static_cast<float*>(workspace);
+  a.dpad = align_up(d, 4);
+  if (e_cap > 0) {
+    const bool wide = d % WIDE == 0 && ldx % WIDE == 0 && ldy % WIDE == 0 &&
+                      reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+    const int rc = wide ? launch_vec<T, WIDE>(a, e_cap, st) : launch_vec<T, 1>(a, e_cap, st);
+    if (rc != LPG_OK) return rc;
+  }
+  hipLaunchKernelGGL((spmm_empty_rows_kernel<T>), dim3(grid_for(N * (d < 64 ? d : 64))), dim3(kBlock), 0, st, a);
+  return check_launch("csr_spmm");
+}
+}  // namespace
+
+LPG_EXPORT int lpg_spmm_chunk_edges(void) { return kChunk; }
+
+LPG_EXPORT int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d) {
+  if (e_cap < 0 || d < 1) return LPG_E_INVALID;
+  return 2 * lpg::ceil_div(e_cap, kChunk) * lpg::align_up(d, 4) * 4 + 256;
+}
+
+LPG_EXPORT int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,
+                                const float* x, int64_t ldx, float* y, int64_t ldy, int64_t N, int64_t e_cap,
+                                int64_t d, const float* row_scale, const float* bias, int act, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  return spmm_entry<float, 4>(plan, rowptr, col, val, x, ldx, y, ldy, N, e_cap, d, row_scale, bias, act, workspace,
+                              workspace_bytes, stream);
+}
+
+LPG_EXPORT int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,
+                                 const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t N, int64_t e_cap,
+                                 int64_t d, const float* row_scale, const float* bias, int act, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  return spmm_entry<uint16_t, 8>(plan, rowptr, col, val, x, ldx, y, ldy, N, e_cap, d, row_scale, bias, act,
+                                 workspace, workspace_bytes, stream);
+}

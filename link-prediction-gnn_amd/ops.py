@@ -1,0 +1,347 @@
+"""Thin torch <-> C-ABI glue: tensors in, raw device pointers + sizes + hipStream_t out.
+
+PyTorch is used only for device memory, streams and dtype bookkeeping; every computation below
+is a kernel of liblpg_hip.so (include/lpg_hip.h).  All tensors must live on a ROCm device.
+"""
+import os
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+_CHECK = os.environ.get("LPG_CHECK_INDICES", "1") != "0"
+_err_flags = {}
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.LpgError(
+                "lpgnn_amd ops run only on a ROCm device (got a CPU tensor); there is no CPU "
+                "fallback in the product path -- the CPU oracle lives under oracle/ for tests only")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def err_flag(device):
+    f = _err_flags.get(device)
+    if f is None:
+        f = torch.zeros(1, dtype=torch.int32, device=device)
+        _err_flags[device] = f
+    return f
+
+
+def raise_if_flagged(device, what="index"):
+    """Reads the device error flag (synchronises).  Out-of-range indices were skipped by the
+    kernels, never dereferenced; surface them the way ATen does on CPU."""
+    f = err_flag(device)
+    v = int(f.item())
+    if v:
+        f.zero_()
+        raise IndexError(f"lpgnn_amd: {what} out of range (flag={v})")
+
+
+def maybe_check(device, what="index"):
+    if _CHECK:
+        raise_if_flagged(device, what)
+
+
+def _c(t, dtype=None):
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------ scatter_add
+def scatter_add_rows(src: Optional[torch.Tensor], index: torch.Tensor, out: torch.Tensor):
+    """out[index[e], :] += src[e, :]  (src None => ones, int64 only).  out is [N] or [N, d]."""
+    lib = _lib.load()
+    _need_gpu(index, out, src)
+    index = _c(index, torch.int64)
+    E = index.numel()
+    N = out.shape[0]
+    d = out.numel() // N if N > 0 else 1
+    assert out.is_contiguous()
+    flag = err_flag(out.device)
+    if out.dtype == torch.int64:
+        src = _c(src, torch.int64)
+        _lib.check(lib.lpg_scatter_add_i64(_ptr(src), _ptr(index), E, d, _ptr(out), N, _ptr(flag), _stream()),
+                   "scatter_add_i64")
+    elif out.dtype == torch.float32:
+        src = _c(src, torch.float32)
+        _lib.check(lib.lpg_scatter_add_f32(_ptr(src), _ptr(index), E, d, _ptr(out), N, _ptr(flag), _stream()),
+                   "scatter_add_f32")
+    else:
+        raise TypeError(f"scatter_add: unsupported dtype {out.dtype} (int64 and float32 are built)")
+    return out
+
+
+# ------------------------------------------------------------------------------ CSR graph
+class CSRGraph:
+    """Destination-major CSR of a graph plus the SpMM plan; built once, reused by every layer.
+
+    rowptr int64 [N+1], col int32 [e_cap], val float32 [e_cap] or None; the number of stored
+    edges is rowptr[N] on the device (<= e_cap), so no host sync is needed to use it.
+    """
+
+    def __init__(self, rowptr, col, val, n_rows, n_cols, e_cap, perm=None, dinv=None):
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.n_rows, self.n_cols, self.e_cap = int(n_rows), int(n_cols), int(e_cap)
+        self.perm, self.dinv = perm, dinv
+        self.device = rowptr.device
+        self._plan = None
+        self._ws = {}
+
+    # -- construction ----------------------------------------------------------------------
+    @staticmethod
+    def from_edge_index(edge_index, n_rows, n_cols=None, edge_weight=None, gcn_self_loops=False,
+                        keep_perm=False):
+        """edge_index [2,E] int64 (row 0 = source, row 1 = destination), PyG convention."""
+        lib = _lib.load()
+        _need_gpu(edge_index, edge_weight)
+        n_cols = n_rows if n_cols is None else n_cols
+        dev = edge_index.device
+        E = edge_index.shape[1]
+        src = _c(edge_index[0], torch.int64)
+        dst = _c(edge_index[1], torch.int64)
+        w = _c(edge_weight, torch.float32)
+        e_cap = E + (n_rows if gcn_self_loops else 0)
+        rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+        col = torch.empty(max(e_cap, 1), dtype=torch.int32, device=dev)
+        need_val = w is not None
+        val = torch.empty(max(e_cap, 1), dtype=torch.float32, device=dev) if need_val else None
+        perm = torch.empty(max(e_cap, 1), dtype=torch.int32, device=dev) if keep_perm else None
+        nbytes = _lib.check(lib.lpg_coo_to_csr_bytes(E, n_rows, int(gcn_self_loops)), "coo_to_csr_bytes")
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        flag = err_flag(dev)
+        _lib.check(lib.lpg_coo_to_csr(_ptr(src), _ptr(dst), _ptr(w), E, n_rows, n_cols, int(gcn_self_loops),
+                                      _ptr(rowptr), _ptr(col), _ptr(val), _ptr(perm), _ptr(ws), nbytes,
+                                      _ptr(flag), _stream()), "coo_to_csr")
+        g = CSRGraph(rowptr, col, val, n_rows, n_cols, e_cap, perm=perm)
+        g._build_plan()
+        raise_if_flagged(dev, "edge_index")     # one sync per graph build
+        return g
+
+    @staticmethod
+    def from_csr(rowptr, col, val, n_cols):
+        _need_gpu(rowptr, col, val)
+        rowptr = _c(rowptr, torch.int64)
+        col = _c(col, torch.int32)
+        val = _c(val, torch.float32)
+        g = CSRGraph(rowptr, col, val, rowptr.numel() - 1, n_cols, col.numel())
+        g._build_plan()
+        raise_if_flagged(rowptr.device, "csr col/rowptr")
+        return g
+
+    def _build_plan(self):
+        lib = _lib.load()
+        nbytes = _lib.check(lib.lpg_csr_plan_bytes(self.n_rows, self.e_cap), "csr_plan_bytes")
+        self._plan = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        _lib.check(lib.lpg_csr_plan_build(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, self.e_cap,
+                                          _ptr(self._plan), nbytes, _ptr(err_flag(self.device)), _stream()),
+                   "csr_plan_build")
+
+    def gcn_normalize_(self):
+        """val <- D^-1/2 val D^-1/2 with D = destination weight sums (PyG gcn_norm)."""
+        lib = _lib.load()
+        if self.val is None:
+            self.val = torch.ones(max(self.e_cap, 1), dtype=torch.float32, device=self.device)
+        self.dinv = torch.empty(max(self.n_rows, 1), dtype=torch.float32, device=self.device)
+        _lib.check(lib.lpg_gcn_norm_csr(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), _ptr(self.dinv),
+                                        self.n_rows, _stream()), "gcn_norm_csr")
+        return self
+
+    def nnz(self):
+        return int(self.rowptr[-1].item())
+
+    # -- the hot op --------------------------------------------------------------------------
+    def _workspace(self, d):
+        lib = _lib.load()
+        nbytes = _lib.check(lib.lpg_csr_spmm_bytes(self.e_cap, d), "csr_spmm_bytes")
+        ws = self._ws.get("spmm")
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws["spmm"] = ws
+        return ws, nbytes
+
+    def spmm(self, x, row_scale=None, bias=None, act=None, out=None, use_val=True):
+        """Y = act(row_scale * (A @ x) + bias);  x [n_cols, d] float32 or bfloat16."""
+        lib = _lib.load()
+        _need_gpu(x, row_scale, bias)
+        if x.dim() != 2 or x.shape[0] != self.n_cols:
+            raise ValueError(f"spmm: x must be [{self.n_cols}, d], got {tuple(x.shape)}")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        d = x.shape[1]
+        if out is None:
+            out = torch.empty((self.n_rows, d), dtype=x.dtype, device=x.device)
+        elif out.shape != (self.n_rows, d) or out.dtype != x.dtype or out.stride(1) != 1:
+            raise ValueError("spmm: bad `out`")
+        row_scale = _c(row_scale, torch.float32)
+        bias = _c(bias, torch.float32)
+        val = self.val if use_val else None
+        ws, nbytes = self._workspace(d)
+        args = (_ptr(self._plan), _ptr(self.rowptr), _ptr(self.col), _ptr(val), _ptr(x), x.stride(0), _ptr(out),
+                out.stride(0), self.n_rows, self.e_cap, d, _ptr(row_scale), _ptr(bias), ACT[act], _ptr(ws), nbytes,
+                _stream())
+        if x.dtype == torch.float32:
+            _lib.check(lib.lpg_csr_spmm_f32(*args), "csr_spmm_f32")
+        elif x.dtype == torch.bfloat16:
+            _lib.check(lib.lpg_csr_spmm_bf16(*args), "csr_spmm_bf16")
+        else:
+            raise TypeError(f"spmm: unsupported dtype {x.dtype}")
+        return out
+
+
+# ------------------------------------------------------------------------------ dense / norm
+def linear(x, weight, bias=None, w_is_km=False, out=None):
+    """x [n,k] @ weight^T (+bias); weight [m,k] (nn.Linear) or [k,m] when w_is_km."""
+    lib = _lib.load()
+    _need_gpu(x, weight, bias)
+    x = _c(x, torch.float32)
+    weight = _c(weight, torch.float32)
+    bias = _c(bias, torch.float32)
+    n, k = x.shape
+    m = weight.shape[1] if w_is_km else weight.shape[0]
+    if (weight.shape[0] if w_is_km else weight.shape[1]) != k:
+        raise ValueError(f"linear: shape mismatch x {tuple(x.shape)} w {tuple(weight.shape)}")
+    if out is None:
+        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    _lib.check(lib.lpg_linear_f32(_ptr(x), x.stride(0), _ptr(weight), int(w_is_km), _ptr(bias), _ptr(out),
+                                  out.stride(0), n, k, m, _stream()), "linear_f32")
+    return out
+
+
+_gn_ws = {}
+
+
+def graph_norm(x, weight, bias, mean_scale, eps=1e-5, relu=False, add_to=None, out=None):
+    lib = _lib.load()
+    _need_gpu(x, weight, bias, mean_scale, add_to)
+    x = _c(x, torch.float32)
+    n, d = x.shape
+    nbytes = _lib.check(lib.lpg_graphnorm_bytes(n, d), "graphnorm_bytes")
+    key = (x.device, "gn")
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _gn_ws[key] = ws
+    if out is None:
+        out = torch.empty_like(x)
+    add_to = _c(add_to, torch.float32)
+    _lib.check(lib.lpg_graphnorm_f32(_ptr(x), n, d, _ptr(_c(weight, torch.float32)), _ptr(_c(bias, torch.float32)),
+                                     _ptr(_c(mean_scale, torch.float32)), float(eps), int(relu), _ptr(add_to),
+                                     _ptr(out), _ptr(ws), ws.numel(), _stream()), "graphnorm_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------ pair ops
+def embedding(table, idx):
+    lib = _lib.load()
+    _need_gpu(table, idx)
+    table = _c(table, torch.float32)
+    idx = _c(idx.reshape(-1), torch.int64)
+    out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    _lib.check(lib.lpg_embedding_f32(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(), _ptr(out),
+                                     _ptr(err_flag(table.device)), _stream()), "embedding")
+    return out
+
+
+def pair_gather_mul(x, pos):
+    lib = _lib.load()
+    _need_gpu(x, pos)
+    x = _c(x, torch.float32)
+    pos = _c(pos, torch.int64)
+    P = pos.shape[0]
+    h = torch.empty((P, x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.lpg_pair_gather_mul_f32(_ptr(x), x.shape[0], x.shape[1], _ptr(pos), P, _ptr(h),
+                                           _ptr(err_flag(x.device)), _stream()), "pair_gather_mul")
+    return h
+
+
+def pair_readout(h, idx, w, b):
+    lib = _lib.load()
+    _need_gpu(h, idx, w, b)
+    h = _c(h, torch.float32)
+    idx = _c(idx.reshape(-1), torch.int64)
+    B = idx.numel() // 2
+    out = torch.empty((B, 1), dtype=torch.float32, device=h.device)
+    _lib.check(lib.lpg_pair_readout_f32(_ptr(h), h.shape[0], h.shape[1], _ptr(idx), B,
+                                        _ptr(_c(w.reshape(-1), torch.float32)), _ptr(_c(b, torch.float32)),
+                                        _ptr(out), _ptr(err_flag(h.device)), _stream()), "pair_readout")
+    return out
+
+
+def flip_index(ei2):
+    lib = _lib.load()
+    _need_gpu(ei2)
+    ei2 = _c(ei2, torch.int64)
+    e, er = torch.empty_like(ei2), torch.empty_like(ei2)
+    _lib.check(lib.lpg_flip_index_i64(_ptr(ei2), ei2.shape[1], _ptr(e), _ptr(er), _stream()), "flip_index")
+    return e, er
+
+
+# ------------------------------------------------------------------------------ tuple graph
+def get_ei2(n_node, pos_edge, pred_edge):
+    """TwoWL/utils.py:36-45 on the device; returns int64 [2, E2] in the reference's order."""
+    lib = _lib.load()
+    _need_gpu(pos_edge, pred_edge)
+    import ctypes
+    pos_edge = _c(pos_edge, torch.int64)
+    pred_edge = _c(pred_edge, torch.int64)
+    E1, Ep = pos_edge.shape[1], pred_edge.shape[1]
+    dev = pos_edge.device
+    nbytes = _lib.check(lib.lpg_get_ei2_bytes(n_node, E1, Ep), "get_ei2_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    e2 = ctypes.c_int64(0)
+    _lib.check(lib.lpg_get_ei2_count(_ptr(pos_edge), E1, _ptr(pred_edge), Ep, n_node, _ptr(ws), nbytes,
+                                     ctypes.addressof(e2), _ptr(err_flag(dev)), _stream()), "get_ei2_count")
+    raise_if_flagged(dev, "get_ei2 node id")
+    E2 = int(e2.value)
+    ei2 = torch.empty((2, E2), dtype=torch.int64, device=dev)
+    _lib.check(lib.lpg_get_ei2_fill(_ptr(ws), n_node, E1, Ep, E2, _ptr(ei2), _stream()), "get_ei2_fill")
+    return ei2
+
+
+def mark(idx, n_mask):
+    lib = _lib.load()
+    idx = _c(idx.reshape(-1), torch.int64)
+    mask = torch.zeros(n_mask, dtype=torch.uint8, device=idx.device)
+    _lib.check(lib.lpg_mark_i64(_ptr(idx), idx.numel(), _ptr(mask), n_mask, _ptr(err_flag(idx.device)), _stream()),
+               "mark")
+    return mask
+
+
+def keep_from_blocked(key, E, blocked, invert=False):
+    lib = _lib.load()
+    key = _c(key, torch.int64)
+    keep = torch.empty(E, dtype=torch.uint8, device=blocked.device)
+    _lib.check(lib.lpg_keep_from_blocked(_ptr(key), E, _ptr(blocked), blocked.numel(), int(invert), _ptr(keep),
+                                         _ptr(err_flag(blocked.device)), _stream()), "keep_from_blocked")
+    return keep
+
+
+def compact_cols(mat, keep):
+    """mat[:, keep != 0] with the column order preserved (stable)."""
+    lib = _lib.load()
+    import ctypes
+    mat = _c(mat, torch.int64)
+    rows, E = mat.shape
+    nbytes = _lib.check(lib.lpg_compact_cols_bytes(E), "compact_cols_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=mat.device)
+    out = torch.empty(max(rows * E, 1), dtype=torch.int64, device=mat.device)
+    cnt = ctypes.c_int64(0)
+    _lib.check(lib.lpg_compact_cols_i64(_ptr(mat), rows, E, _ptr(keep), _ptr(out), _ptr(ws), nbytes,
+                                        ctypes.addressof(cnt), _stream()), "compact_cols")
+    c = int(cnt.value)
+    return out[: rows * c].view(rows, c)

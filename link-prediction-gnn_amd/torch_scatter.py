@@ -1,0 +1,105 @@
+"""Drop-in for the ``torch_scatter`` call surface the reference uses.
+
+Reference call site: TwoWL/utils.py:5,10 -- ``from torch_scatter import scatter_add`` inside the
+``@torch.jit.script`` function ``degree``.  Signature kept from torch-scatter 2.1.1 [3P]:
+    scatter_add(src, index, dim=-1, out=None, dim_size=None) -> Tensor   (alias of scatter_sum)
+``index`` is broadcast to ``src`` along every dim but ``dim``; with ``out=None`` the result is
+zeros with size[dim] = dim_size or index.max()+1.
+
+The function body is TorchScript-compatible and dispatches to registered torch ops
+(``torch.ops.lpgnn.*``), so scripted callers such as ``degree`` keep working.  The ops run the
+HIP kernels lpg_scatter_add_{i64,f32}; CPU tensors raise (no fallback).
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import ops as _ops
+
+_lib = torch.library.Library("lpgnn", "DEF")
+_lib.define("scatter_add(Tensor src, Tensor index, int dim, int? dim_size) -> Tensor")
+_lib.define("scatter_add_out(Tensor src, Tensor index, int dim, Tensor(a!) out) -> ()")
+
+
+def _rows_view(src, index, dim):
+    """Move `dim` first and flatten the rest: the kernels scatter whole rows."""
+    dim = dim if dim >= 0 else src.dim() + dim
+    if index.dim() == 1 and src.dim() >= 1 and (dim == 0 or src.dim() == 1):
+        if index.numel() != src.shape[dim]:
+            raise ValueError("scatter_add: index length does not match src along dim")
+        return dim, src.reshape(src.shape[0], -1) if src.dim() > 1 else src, index, None
+    # general case: index broadcast to src (torch_scatter.utils.broadcast), element-wise scatter
+    idx = index
+    if idx.dim() == 1:
+        shape = [1] * src.dim()
+        shape[dim] = -1
+        idx = idx.view(shape)
+    idx = idx.expand_as(src)
+    return dim, src, idx, True
+
+
+def _impl_into(src, index, dim, out):
+    dim, s, idx, general = _rows_view(src, index, dim)
+    if general is None:
+        o = out.view(out.shape[0], -1) if out.dim() > 1 else out
+        if not o.is_contiguous():
+            raise ValueError("scatter_add: `out` must be contiguous")
+        _ops.scatter_add_rows(s, idx, o)
+    else:
+        # element-wise: flatten to a 1-D scatter with linearised destination offsets
+        src_m = s.movedim(dim, -1)
+        idx_m = idx.movedim(dim, -1)
+        out_m = out.movedim(dim, -1)
+        if not out_m.is_contiguous():
+            raise ValueError("scatter_add: unsupported `out` layout for dim != 0")
+        lead = out_m.numel() // out_m.shape[-1] if out_m.shape[-1] else 0
+        base = torch.arange(lead, device=src.device, dtype=torch.int64).view(out_m.shape[:-1] + (1,)) * out_m.shape[-1]
+        # bounds: an index >= out.shape[dim] must be flagged, not alias a neighbour row
+        bad = (idx_m < 0) | (idx_m >= out_m.shape[-1])
+        lin = torch.where(bad, torch.full_like(idx_m, -1), idx_m + base)
+        _ops.scatter_add_rows(src_m.reshape(-1), lin.reshape(-1), out_m.view(-1))
+    _ops.maybe_check(out.device, "scatter_add index")
+
+
+def _scatter_add(src, index, dim, dim_size):
+    d = dim if dim >= 0 else src.dim() + dim
+    size = list(src.shape)
+    if dim_size is not None:
+        size[d] = int(dim_size)
+    elif index.numel() == 0:
+        size[d] = 0
+    else:
+        size[d] = int(index.max()) + 1
+    out = torch.zeros(size, dtype=src.dtype, device=src.device)
+    _impl_into(src, index, dim, out)
+    return out
+
+
+def _scatter_add_out(src, index, dim, out):
+    _impl_into(src, index, dim, out)
+
+
+_lib.impl("scatter_add", _scatter_add, "CompositeExplicitAutograd")
+_lib.impl("scatter_add_out", _scatter_add_out, "CompositeExplicitAutograd")
+
+
+def scatter_sum(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                dim_size: Optional[int] = None) -> Tensor:
+    if out is None:
+        return torch.ops.lpgnn.scatter_add(src, index, dim, dim_size)
+    else:
+        torch.ops.lpgnn.scatter_add_out(src, index, dim, out)
+        return out
+
+
+def scatter_add(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                dim_size: Optional[int] = None) -> Tensor:
+    return scatter_sum(src, index, dim, out, dim_size)
+
+
+def scatter(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+            dim_size: Optional[int] = None, reduce: str = "sum") -> Tensor:
+    if reduce == "sum" or reduce == "add":
+        return scatter_sum(src, index, dim, out, dim_size)
+    raise ValueError("lpgnn_amd.torch_scatter: only reduce='sum'/'add' is on the reference's path")

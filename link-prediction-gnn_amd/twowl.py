@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference's TwoWL hot path (same names, argument meaning, layouts).
+
+    degree / reverse / double / get_ei2 / sample_block     <-> TwoWL/utils.py:8-90
+    Seq / LocalWLNet                                        <-> TwoWL/model/model.py:8-96
+    test_forward                                            <-> TwoWL/model/train.py:50-60
+
+Every tensor op below is a kernel of liblpg_hip.so.  state_dict keys equal the reference's, so
+weights trained with the reference load unchanged.  Eval-mode forward only.
+"""
+import torch
+from torch import nn
+
+from . import ops as _ops
+from .nn import GCNConv, GraphNorm, _forward_only
+from .torch_scatter import scatter_add
+
+
+def degree(ei, num_node: int):
+    """TwoWL/utils.py:8-10 -- in-degree histogram over ei[1]; int64, bit-exact."""
+    return scatter_add(torch.ones_like(ei[1]), ei[1], dim_size=num_node)
+
+
+def reverse(edge_index):
+    """TwoWL/utils.py:71-78 -- (edge, edge_r) with the partner-direction tuple id flipped."""
+    return _ops.flip_index(edge_index)
+
+
+def double(x, for_index=False):
+    """TwoWL/utils.py:81-90 (layout glue, host-side reshapes only)."""
+    if not for_index:
+        row, col = x[0].reshape(1, x.shape[1]), x[1].reshape(1, x.shape[1])
+        x = torch.cat([row, col, col, row], 0).t()
+        return x.reshape(-1, 2).t()
+    x = x.reshape(1, x.shape[0])
+    x = torch.cat([2 * x, 2 * x + 1], 0).t()
+    return x.reshape(-1, 1).t().squeeze()
+
+
+class Seq(nn.Module):
+    """TwoWL/model/model.py:87-96; when the list is [GCNConv, GraphNorm, Dropout, ReLU|Identity]
+    the norm, the (eval-mode identity) dropout and the activation run as ONE fused kernel."""
+
+    def __init__(self, modlist):
+        super().__init__()
+        self.modlist = nn.ModuleList(modlist)
+
+    def forward(self, *args, add_to=None, **kwargs):
+        _forward_only(self)
+        mods = list(self.modlist)
+        out = mods[0](*args, **kwargs)
+        if (len(mods) == 4 and isinstance(mods[1], GraphNorm) and isinstance(mods[2], nn.Dropout)
+                and isinstance(mods[3], (nn.ReLU, nn.Identity))):
+            return mods[1](out, relu=isinstance(mods[3], nn.ReLU), add_to=add_to)
+        for m in mods[1:]:
+            out = m(out)
+        return out if add_to is None else out + add_to
+
+
+class LocalWLNet(nn.Module):
+    """TwoWL/model/model.py:8-84 (degree-embedding variant, use_node_feat=False)."""
+
+    def __init__(self, max_x, use_node_feat=False, node_feat=None, channels_1wl=256, channels_2wl=32, depth1=1,
+                 depth2=1, dp_lin0=0.7, dp_lin1=0.7, dp_emb=0.5, dp_1wl0=0.5, dp_2wl=0.5, dp_1wl1=0.5, act0=True,
+                 act1=True):
+        super().__init__()
+        if use_node_feat:
+            raise NotImplementedError("fb-pages-food has no node features; the reference path uses the "
+                                      "degree embedding (TwoWL/operators/datasets.py:107-114)")
+
+        def relu_conv(insize, outsize, dp, act):
+            return Seq([GCNConv(insize, outsize), GraphNorm(outsize), nn.Dropout(p=dp, inplace=True),
+                        nn.ReLU(inplace=True) if act else nn.Identity()])
+
+        self.max_x, self.use_node_feat, self.node_feat = max_x, use_node_feat, node_feat
+        self.emb = nn.Sequential(nn.Embedding(max_x + 1, channels_1wl), GraphNorm(channels_1wl),
+                                 nn.Dropout(p=dp_emb, inplace=True))
+        self.conv1s = nn.ModuleList([relu_conv(channels_1wl, channels_1wl, dp_1wl0, act0) for _ in range(depth1 - 1)]
+                                    + [relu_conv(channels_1wl, channels_2wl, dp_1wl1, act1)])
+        self.conv2s = nn.ModuleList([relu_conv(channels_2wl, channels_2wl, dp_2wl, True) for _ in range(depth2)])
+        self.conv2s_r = nn.ModuleList([relu_conv(channels_2wl, channels_2wl, dp_2wl, True) for _ in range(depth2)])
+        self.pred = nn.Linear(channels_2wl, 1)
+
+    def forward(self, x, edge1, pos, idx=None, ei2=None, test=False):
+        _forward_only(self)
+        edge2, edge2_r = reverse(ei2)                                  # K8
+        x = _ops.embedding(self.emb[0].weight, x)                      # Embedding(deg)
+        x = self.emb[1](x)                                             # GraphNorm (Dropout: eval identity)
+        for conv1 in self.conv1s:
+            x = conv1(x, edge1)                                        # K5 + K3/K4 + K6
+        x = _ops.pair_gather_mul(x, pos)                               # K7
+        for i in range(len(self.conv2s)):
+            a = self.conv2s[i](x, edge2)
+            x = self.conv2s_r[i](x, edge2_r, add_to=a)                 # a7: both orientations, summed
+        out = _ops.pair_readout(x, idx, self.pred.weight, self.pred.bias)   # K9
+        _ops.maybe_check(out.device, "LocalWLNet index")
+        return out
+
+    def export_params(self):
+        """plain-numpy parameter dict in the layout oracle.aggregation.localwl_forward reads."""
+        p = {"depth1": len(self.conv1s), "depth2": len(self.conv2s)}
+        t = lambda v: v.detach().cpu().double().numpy()
+        p["emb.weight"] = t(self.emb[0].weight)
+        for k in ("weight", "bias", "mean_scale"):
+            p[f"emb_norm.{k}"] = t(getattr(self.emb[1], k))
+        for name in ("conv1s", "conv2s", "conv2s_r"):
+            for l, seq in enumerate(getattr(self, name)):
+                conv, norm, act = seq.modlist[0], seq.modlist[1], seq.modlist[3]
+                p[f"{name}.{l}.lin.weight"] = t(conv.lin.weight)
+                p[f"{name}.{l}.bias"] = t(conv.bias)
+                for k in ("weight", "bias", "mean_scale"):
+                    p[f"{name}.{l}.norm.{k}"] = t(getattr(norm, k))
+                p[f"{name}.{l}.act"] = isinstance(act, nn.ReLU)
+        p["pred.weight"], p["pred.bias"] = t(self.pred.weight), t(self.pred.bias)
+        return p
+
+
+@torch.no_grad()
+def test_forward(mod, x, ei, pos1, y_len, ei2):
+    """the timed scoring forward of TwoWL/model/train.py:54-60."""
+    mod.eval()
+    idx = ei.shape[1] + torch.arange(y_len, device=x.device)
+    return mod(x, ei, pos1, idx, ei2, True)
+
+
+def get_ei2(n_node: int, pos_edge, pred_edge):
+    """TwoWL/utils.py:36-45 -- 2-WL tuple graph, bit-exact incl. order (segmented cartesian
+    product on the device instead of the O(N*P) mask loop)."""
+    return _ops.get_ei2(n_node, pos_edge, pred_edge)
+
+
+def idx2mask(num: int, idx):
+    """TwoWL/utils.py:53-57."""
+    return _ops.mark(idx, num).bool()
+
+
+def blockei2(ei2, blocked_idx, n_tuples=None):
+    """TwoWL/utils.py:48-50 -- drop tuple-graph edges whose SOURCE tuple is blocked."""
+    n_tuples = int(n_tuples) if n_tuples is not None else int(max(ei2.max().item(), blocked_idx.max().item())) + 1
+    blocked = _ops.mark(blocked_idx, n_tuples)
+    keep = _ops.keep_from_blocked(ei2[0], ei2.shape[1], blocked)
+    out = _ops.compact_cols(ei2, keep)
+    _ops.maybe_check(ei2.device, "blockei2 index")
+    return out
+
+
+def sample_block(sample_idx, size, ei, ei2=None, n_tuples=None):
+    """TwoWL/utils.py:61-68 -- (ei_new, x_new, ei2_new); x_new = kept edges per SOURCE node."""
+    E = ei.shape[1]
+    blocked = _ops.mark(sample_idx, E)
+    keep = _ops.keep_from_blocked(None, E, blocked)
+    ei_new = _ops.compact_cols(ei, keep)
+    ei2_new = blockei2(ei2, sample_idx, n_tuples) if ei2 is not None else None
+    x_new = torch.zeros(size, dtype=torch.int64, device=ei.device)
+    _ops.scatter_add_rows(None, ei_new[0], x_new)
+    _ops.maybe_check(ei.device, "sample_block index")
+    return ei_new, x_new, ei2_new

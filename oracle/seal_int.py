@@ -43,12 +43,17 @@ def enclosing_nodes(node_pair, A, hop, max_neighbors=100):
     if int(hop) not in (0, 1):
         raise ValueError("reference crashes for hop >= 2; only hop 0/1 are defined")
     if int(hop) == 1:
-        for node in (u, v):      # order only matters in the capped branch
-            nb = neighbours(A, node)
-            if len(sub) + len(nb) < max_neighbors:
-                sub |= set(int(x) for x in nb)
-            else:
-                return None, True
+        # the reference visits [u, v] in a shuffled order (:122); report `capped` when the
+        # truncation branch (:124-130) would fire in EITHER order
+        for first, second in ((u, v), (v, u)):
+            s = {u, v}
+            for node in (first, second):
+                nb = neighbours(A, node)
+                if len(s) + len(nb) < max_neighbors:
+                    s |= set(int(x) for x in nb)
+                else:
+                    return None, True
+        sub = s
     sub.discard(u)
     sub.discard(v)
     return [u, v] + sorted(sub), False

@@ -1,0 +1,75 @@
+"""CPU, world_size 2, gloo: the N > 1 path -- source-edge partition + all-reduce of the partial
+node aggregates, row-block pipelined -- must reproduce the single-process result.  The per-block
+SpMM is supplied by the fp64 oracle here (there is no GPU in this container); on the GPU the same
+class runs the HIP CSR kernels and RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lpgnn_amd import dist as ldist
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(0)                      # identical on every rank
+    n, e, d = 203, 5000, 12
+    ei = rng.integers(0, n, size=(2, e)).astype(np.int64)
+    x = rng.standard_normal((n, d))
+    lo, hi = ldist.source_range(n, world, rank)
+    mine = ldist.partition_edges_by_source(torch.from_numpy(ei), n, world, rank).numpy()
+    assert mine.shape[1] > 0 and mine[0].min() >= lo and mine[0].max() < hi
+
+    def block_spmm(k, r0, r1, x_local):
+        m = (mine[1] >= r0) & (mine[1] < r1)
+        rowptr, col, _, _ = agg.coo_to_csr(mine[1][m] - r0, mine[0][m] - lo, r1 - r0)
+        return torch.from_numpy(agg.csr_spmm(rowptr, col, None, x_local.numpy()))
+
+    op = ldist.SourcePartitionedSpMM(torch.from_numpy(mine), n, (lo, hi), n_blocks=5, block_spmm=block_spmm)
+    y = op.forward(torch.from_numpy(x[lo:hi]))
+    rowptr, col, _, _ = agg.coo_to_csr(ei[1], ei[0], n)
+    want = agg.csr_spmm(rowptr, col, None, x)
+    q.put((rank, float(np.abs(y.numpy() - want).max()), mine.shape[1]))
+    dist.destroy_process_group()
+
+
+def test_source_partition_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(r[2] for r in res) == 5000                 # every edge owned by exactly one rank
+    for _, err, _ in res:
+        assert err < 1e-12
+
+
+def test_ranges_cover_and_balance():
+    from lpgnn_amd import dist as ldist
+    for n, w in [(10, 3), (5_000_000, 8), (7, 8), (1, 1)]:
+        r = [ldist.source_range(n, w, k) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+        sizes = [b - a for a, b in r]
+        assert max(sizes) - min(sizes) <= 1
+    assert ldist.row_blocks(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]

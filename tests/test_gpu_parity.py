@@ -1,0 +1,493 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures.  Integer / index work: bit-exact.  Float aggregation: |y - y64| <= 1e-5 * sum_e |w_e x_e|
+(the north star's 1e-5 relative bar, taken relative to the magnitude actually summed so that
+cancelling rows are not held to an impossible per-element ratio) -- the tolerance is TOL below.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import lpgnn_amd
+    lpgnn_amd.load_library()          # fails loudly if the HIP extension is missing
+    return torch.device("cuda:0")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def rand_graph(rng, n_rows, n_cols, E, hub=None, empty_frac=0.0):
+    dst = rng.integers(0, n_rows, size=E)
+    if hub is not None and E:
+        dst[: int(hub * E)] = rng.integers(0, n_rows)          # one heavy destination row
+    if empty_frac and n_rows > 4:
+        dead = rng.choice(n_rows, size=int(empty_frac * n_rows), replace=False)
+        dst = dst[~np.isin(dst, dead)]
+    src = rng.integers(0, n_cols, size=dst.size)
+    return np.stack([src, dst]).astype(np.int64)
+
+
+# ------------------------------------------------------------------ scatter_add / degree (a1)
+def test_degree_bit_exact(dev):
+    from lpgnn_amd.twowl import degree
+    from oracle import twowl_int
+    rng = np.random.default_rng(0)
+    for n, E in [(620, 3288), (1, 5), (50000, 200000), (7, 0)]:
+        ei = rng.integers(0, n, size=(2, E)).astype(np.int64)
+        got = degree(torch.from_numpy(ei).to(dev), n)
+        assert got.dtype == torch.int64 and np.array_equal(_np(got), twowl_int.degree(ei, n))
+
+
+def test_scatter_add_variants(dev):
+    from lpgnn_amd.torch_scatter import scatter_add
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(1)
+    n, E, d = 300, 5000, 24
+    idx = rng.integers(0, n, size=E)
+    src_i = rng.integers(-50, 50, size=(E, d)).astype(np.int64)
+    got = scatter_add(torch.from_numpy(src_i).to(dev), torch.from_numpy(idx).to(dev), dim=0, dim_size=n)
+    assert np.array_equal(_np(got), agg.scatter_add(src_i, idx, n))
+    src_f = rng.standard_normal((E, d)).astype(np.float32)
+    got = scatter_add(torch.from_numpy(src_f).to(dev), torch.from_numpy(idx).to(dev), dim=0, dim_size=n)
+    want = agg.scatter_add(src_f.astype(np.float64), idx, n)
+    scale = agg.scatter_add(np.abs(src_f).astype(np.float64), idx, n)
+    assert np.all(np.abs(_np(got) - want) <= TOL * scale + 1e-30)
+    # out= accumulates; dim_size inferred from index.max()+1
+    out = torch.ones(n, dtype=torch.int64, device=dev)
+    scatter_add(torch.ones(E, dtype=torch.int64, device=dev), torch.from_numpy(idx).to(dev), out=out)
+    assert np.array_equal(_np(out), 1 + np.bincount(idx, minlength=n))
+    got = scatter_add(torch.ones(E, dtype=torch.int64, device=dev), torch.from_numpy(idx).to(dev))
+    assert got.shape[0] == idx.max() + 1
+    # dim=1 (index broadcast along rows), as torch_scatter allows
+    src2 = rng.integers(0, 9, size=(4, 50)).astype(np.int64)
+    idx2 = rng.integers(0, 10, size=50)
+    got = scatter_add(torch.from_numpy(src2).to(dev), torch.from_numpy(idx2).to(dev), dim=1, dim_size=10)
+    want = np.zeros((4, 10), dtype=np.int64)
+    for r in range(4):
+        np.add.at(want[r], idx2, src2[r])
+    assert np.array_equal(_np(got), want)
+
+
+def test_scatter_add_out_of_range_raises(dev):
+    from lpgnn_amd.torch_scatter import scatter_add
+    idx = torch.tensor([0, 5, 2], device=dev)
+    with pytest.raises(IndexError):
+        scatter_add(torch.ones(3, dtype=torch.int64, device=dev), idx, dim_size=3)
+    # flag is cleared: the next valid call works
+    got = scatter_add(torch.ones(3, dtype=torch.int64, device=dev), idx, dim_size=6)
+    assert _np(got).tolist() == [1, 0, 1, 0, 0, 1]
+
+
+# ------------------------------------------------------------------ COO -> CSR, gcn_norm (K3)
+@pytest.mark.parametrize("loops", [False, True])
+def test_coo_to_csr_and_gcn_norm(dev, loops):
+    import lpgnn_amd
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(2)
+    n, E = 500, 6000
+    ei = rand_graph(rng, n, n, E, empty_frac=0.1)
+    ei[:, :40] = np.stack([np.arange(40), np.arange(40)])         # existing self loops
+    w = rng.uniform(0.1, 2.0, size=ei.shape[1]).astype(np.float32)
+    for weight in (None, w):
+        g = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n, n,
+                                               None if weight is None else torch.from_numpy(weight).to(dev),
+                                               gcn_self_loops=loops, keep_perm=True)
+        if loops:
+            ei_o, w_o = agg.add_remaining_self_loops(ei, weight, n)
+        else:
+            ei_o, w_o = ei, (np.ones(ei.shape[1]) if weight is None else weight.astype(np.float64))
+        rowptr, col, val, perm = agg.coo_to_csr(ei_o[1], ei_o[0], n, w_o)
+        nnz = g.nnz()
+        assert nnz == ei_o.shape[1]
+        assert np.array_equal(_np(g.rowptr), rowptr)
+        assert np.array_equal(_np(g.col[:nnz]), col)                # incl. in-row order
+        if weight is not None:
+            assert np.array_equal(_np(g.val[:nnz]), val.astype(np.float32))
+        if loops:
+            g.gcn_normalize_()
+            ei_n, w_n = agg.gcn_norm(ei, n, weight)
+            _, _, val_n, _ = agg.coo_to_csr(ei_n[1], ei_n[0], n, w_n)
+            assert np.allclose(_np(g.val[:nnz]), val_n, rtol=1e-5, atol=0)
+
+
+def test_coo_to_csr_bad_index_raises(dev):
+    import lpgnn_amd
+    ei = torch.tensor([[0, 1, 9], [1, 2, 0]], device=dev)
+    with pytest.raises(IndexError):
+        lpgnn_amd.CSRGraph.from_edge_index(ei, 3, 3)
+
+
+# ------------------------------------------------------------------ CSR SpMM (K4 / K10)
+def _check_spmm(dev, rng, n_rows, n_cols, E, d, weighted, hub=None, empty_frac=0.0, scale=False, bias=False, act=None,
+                dtype=torch.float32):
+    import lpgnn_amd
+    from oracle import aggregation as agg
+    ei = rand_graph(rng, n_rows, n_cols, E, hub=hub, empty_frac=empty_frac)
+    w = rng.uniform(-1, 1, size=ei.shape[1]).astype(np.float32) if weighted else None
+    x = rng.standard_normal((n_cols, d)).astype(np.float32)
+    rs = rng.uniform(0.1, 1.0, size=n_rows).astype(np.float32) if scale else None
+    b = rng.standard_normal(d).astype(np.float32) if bias else None
+    xt = torch.from_numpy(x).to(dev).to(dtype)
+    g = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n_rows, n_cols,
+                                           None if w is None else torch.from_numpy(w).to(dev))
+    y = g.spmm(xt, row_scale=None if rs is None else torch.from_numpy(rs).to(dev),
+               bias=None if b is None else torch.from_numpy(b).to(dev), act=act)
+    y2 = g.spmm(xt, row_scale=None if rs is None else torch.from_numpy(rs).to(dev),
+                bias=None if b is None else torch.from_numpy(b).to(dev), act=act)
+    assert torch.equal(y, y2), "SpMM must be bitwise reproducible"
+    x64 = _np(xt.float()).astype(np.float64)
+    rowptr, col, val, _ = agg.coo_to_csr(ei[1], ei[0], n_rows, w)
+    want = agg.csr_spmm(rowptr, col, val, x64, rs, b, act)
+    mag = agg.spmm_abs_rowsum(rowptr, col, val, x64)
+    if rs is not None:
+        mag = mag * rs[:, None]
+    if b is not None:
+        mag = mag + np.abs(b)[None, :]
+    got = _np(y.float()).astype(np.float64)
+    if dtype == torch.float32:
+        assert np.all(np.abs(got - want) <= TOL * mag + 1e-30), float(np.max(np.abs(got - want) / (mag + 1e-30)))
+    else:   # bf16 output: one rounding of the fp32 accumulator (2^-8 relative) on top
+        assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + TOL * mag + 1e-30)
+
+
+@pytest.mark.parametrize("d", [1, 3, 4, 8, 16, 24, 32, 64, 100, 128, 256, 260, 512])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_feature_widths(dev, d, weighted):
+    _check_spmm(dev, np.random.default_rng(10 + d), 700, 650, 9000, d, weighted, empty_frac=0.2)
+
+
+@pytest.mark.parametrize("case", ["hub", "empty", "tiny", "one_row", "epilogue_tanh", "epilogue_relu", "rect"])
+def test_spmm_shapes(dev, case):
+    rng = np.random.default_rng(20)
+    if case == "hub":          # one row spans many chunks; neighbours straddle chunk borders
+        _check_spmm(dev, rng, 3000, 3000, 60000, 128, True, hub=0.5)
+        _check_spmm(dev, rng, 3000, 3000, 60000, 32, False, hub=0.3)
+    elif case == "empty":      # no edges at all, and N with mostly empty rows
+        _check_spmm(dev, rng, 100, 100, 0, 16, False, bias=True, act="tanh")
+        _check_spmm(dev, rng, 5000, 50, 300, 128, True, empty_frac=0.5, bias=True)
+    elif case == "tiny":
+        _check_spmm(dev, rng, 1, 1, 1, 4, True)
+        _check_spmm(dev, rng, 2, 3, 5, 1, False)
+    elif case == "one_row":    # every edge in one destination row (pure carry chain)
+        _check_spmm(dev, rng, 4, 1000, 5000, 64, True, hub=1.0)
+    elif case == "epilogue_tanh":
+        _check_spmm(dev, rng, 900, 900, 20000, 32, True, scale=True, act="tanh")
+    elif case == "epilogue_relu":
+        _check_spmm(dev, rng, 900, 900, 20000, 24, False, scale=True, bias=True, act="relu")
+    elif case == "rect":
+        _check_spmm(dev, rng, 200, 5000, 30000, 128, True)
+
+
+@pytest.mark.parametrize("d", [8, 64, 128, 256, 20])
+def test_spmm_bf16(dev, d):
+    _check_spmm(dev, np.random.default_rng(30 + d), 2000, 2000, 50000, d, d % 16 == 0, hub=0.2, dtype=torch.bfloat16)
+
+
+def test_spmm_chunk_border_exhaustive(dev):
+    """rows whose edge runs start / end exactly on, one before and one after chunk borders."""
+    import lpgnn_amd
+    from oracle import aggregation as agg
+    T = lpgnn_amd.load_library().lpg_spmm_chunk_edges()
+    rng = np.random.default_rng(3)
+    lens = [T - 1, 1, T, T + 1, 0, 2 * T, 1, 1, T - 2, 3 * T + 5, 0, 0, 7]
+    n_rows, n_cols, d = len(lens), 97, 32
+    dst = np.repeat(np.arange(n_rows), lens)
+    src = rng.integers(0, n_cols, size=dst.size)
+    ei = np.stack([src, dst]).astype(np.int64)
+    x = rng.standard_normal((n_cols, d)).astype(np.float32)
+    g = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n_rows, n_cols)
+    y = _np(g.spmm(torch.from_numpy(x).to(dev)))
+    rowptr, col, _, _ = agg.coo_to_csr(dst, src, n_rows)
+    want = agg.csr_spmm(rowptr, col, None, x)
+    mag = agg.spmm_abs_rowsum(rowptr, col, None, x)
+    assert np.all(np.abs(y - want) <= TOL * mag + 1e-30)
+    assert np.all(y[[4, 10, 11]] == 0)
+
+
+def test_torch_sparse_signatures(dev):
+    from lpgnn_amd.torch_sparse import SparseTensor, matmul, spmm
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(4)
+    m, n, nnz, k = 60, 80, 700, 16
+    row, col = rng.integers(0, m, nnz), rng.integers(0, n, nnz)
+    val = rng.standard_normal(nnz).astype(np.float32)
+    mat = rng.standard_normal((n, k)).astype(np.float32)
+    index = torch.from_numpy(np.stack([row, col])).to(dev)
+    got = spmm(index, torch.from_numpy(val).to(dev), m, n, torch.from_numpy(mat).to(dev))
+    rp, c, v, _ = agg.coo_to_csr(row, col, m, val)
+    want = agg.csr_spmm(rp, c, v, mat)
+    mag = agg.spmm_abs_rowsum(rp, c, v, mat)
+    assert np.all(np.abs(_np(got) - want) <= TOL * mag + 1e-30)
+    st = SparseTensor(row=index[0], col=index[1], value=torch.from_numpy(val).to(dev), sparse_sizes=(m, n))
+    assert np.all(np.abs(_np(matmul(st, torch.from_numpy(mat).to(dev))) - want) <= TOL * mag + 1e-30)
+    rp_t, col_t, val_t = st.csr()
+    st2 = SparseTensor(rowptr=rp_t, col=col_t, value=val_t, sparse_sizes=(m, n))
+    assert torch.equal(st2 @ torch.from_numpy(mat).to(dev), matmul(st, torch.from_numpy(mat).to(dev)))
+
+
+# ------------------------------------------------------------------ dense linear, GraphNorm, pair ops
+@pytest.mark.parametrize("n,k,m", [(620, 256, 32), (4252, 32, 32), (1000, 106, 32), (333, 32, 1), (129, 24, 16), (5, 3, 2)])
+def test_linear_mfma(dev, n, k, m):
+    from lpgnn_amd import ops
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    w = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32)
+    want = x.astype(np.float64) @ w.astype(np.float64).T + b
+    mag = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+    got = _np(ops.linear(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)))
+    assert np.all(np.abs(got - want) <= TOL * mag)
+    got = _np(ops.linear(torch.from_numpy(x).to(dev), torch.from_numpy(w.T.copy()).to(dev), None, w_is_km=True))
+    assert np.all(np.abs(got - (want - b)) <= TOL * mag)
+
+
+@pytest.mark.parametrize("n,d", [(620, 256), (4252, 32), (100000, 24), (3, 5), (70000, 300)])
+def test_graph_norm(dev, n, d):
+    from lpgnn_amd import ops
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(d)
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.1, 3, size=d) + rng.uniform(-5, 5, size=d)).astype(np.float32)
+    w, b, ms = (rng.uniform(0.5, 1.5, d).astype(np.float32), rng.standard_normal(d).astype(np.float32),
+                rng.uniform(0.5, 1.2, d).astype(np.float32))
+    add = rng.standard_normal((n, d)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    want = agg.graph_norm(x, w, b, ms)
+    got = _np(ops.graph_norm(t(x), t(w), t(b), t(ms)))
+    scale = np.abs(want) + np.abs(b)[None, :] + 1.0
+    assert np.all(np.abs(got - want) <= TOL * scale)
+    got = _np(ops.graph_norm(t(x), t(w), t(b), t(ms), relu=True, add_to=t(add)))
+    assert np.all(np.abs(got - (np.maximum(want, 0) + add)) <= TOL * (scale + np.abs(add)))
+
+
+def test_pair_ops_and_flip(dev):
+    from lpgnn_amd import ops
+    from oracle import aggregation as agg, twowl_int
+    rng = np.random.default_rng(5)
+    n, d, P, B = 620, 32, 4252, 386
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    pos = rng.integers(0, n, size=(P, 2))
+    h = ops.pair_gather_mul(torch.from_numpy(x).to(dev), torch.from_numpy(pos).to(dev))
+    assert np.array_equal(_np(h), x[pos[:, 0]] * x[pos[:, 1]])            # one fp32 multiply: exact
+    idx = rng.integers(0, P, size=2 * B)
+    w, b = rng.standard_normal((1, d)).astype(np.float32), rng.standard_normal(1).astype(np.float32)
+    s = ops.pair_readout(h, torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev))
+    hh = _np(h).astype(np.float64)
+    want = agg.pair_readout(hh, idx, w, b)
+    mag = np.abs(hh[idx[0::2]] * hh[idx[1::2]]) @ np.abs(w).T.astype(np.float64) + np.abs(b)
+    assert s.shape == (B, 1) and np.all(np.abs(_np(s) - want) <= TOL * mag)
+    ei2 = rng.integers(0, 8000, size=(2, 70001)).astype(np.int64)
+    e, er = ops.flip_index(torch.from_numpy(ei2).to(dev))
+    we, wer = twowl_int.reverse(ei2)
+    assert np.array_equal(_np(e), we) and np.array_equal(_np(er), wer)
+    emb = rng.standard_normal((110, 24)).astype(np.float32)
+    deg = rng.integers(0, 110, size=620)
+    assert np.array_equal(_np(ops.embedding(torch.from_numpy(emb).to(dev), torch.from_numpy(deg).to(dev))), emb[deg])
+
+
+# ------------------------------------------------------------------ TwoWL integer path vs the reference's goldens
+@pytest.fixture(scope="module")
+def tw(golden_dir):
+    return np.load(os.path.join(golden_dir, "twowl_int.npz"))
+
+
+@pytest.mark.parametrize("split", ["train", "val", "test"])
+def test_get_ei2_reverse_golden(dev, tw, split):
+    from lpgnn_amd import twowl
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
+    ei2 = twowl.get_ei2(620, t(tw[f"{split}_ei"]), t(tw[f"{split}_pred"]))
+    assert ei2.dtype == torch.int64 and np.array_equal(_np(ei2), tw[f"{split}_ei2"])     # incl. order
+    e, er = twowl.reverse(ei2)
+    assert np.array_equal(_np(e), tw[f"{split}_rev"]) and np.array_equal(_np(er), tw[f"{split}_rev_r"])
+    assert np.array_equal(_np(twowl.degree(t(tw[f"{split}_ei"]), 620)), tw[f"{split}_degree_restated3p"])
+
+
+def test_sample_block_golden(dev, tw):
+    from lpgnn_amd import twowl
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
+    P = tw["train_ei"].shape[1] + tw["train_pred"].shape[1]
+    ei_new, x_new, ei2_new = twowl.sample_block(t(tw["sb_idx"]), 620, t(tw["train_ei"]), t(tw["train_ei2"]), n_tuples=P)
+    assert np.array_equal(_np(ei_new), tw["sb_ei_new"])
+    assert np.array_equal(_np(x_new), tw["sb_x_new"])
+    assert np.array_equal(_np(ei2_new), tw["sb_ei2_new"])
+    assert np.array_equal(_np(twowl.double(t(tw["split_train_pos"]))), tw["double_train_pos"])
+    assert np.array_equal(_np(twowl.double(t(tw["double_idx_in"]), for_index=True)), tw["double_idx_out"])
+
+
+def test_get_ei2_edge_cases(dev):
+    from lpgnn_amd import twowl
+    from oracle import twowl_int
+    rng = np.random.default_rng(6)
+    for n, E1, Ep in [(5, 0, 4), (5, 6, 0), (1, 3, 2), (40, 300, 200)]:
+        pe = rng.integers(0, n, size=(2, E1)).astype(np.int64)
+        pr = rng.integers(0, n, size=(2, Ep)).astype(np.int64)
+        got = twowl.get_ei2(n, torch.from_numpy(pe).to(dev), torch.from_numpy(pr).to(dev))
+        assert np.array_equal(_np(got), twowl_int.get_ei2(n, pe, pr))
+
+
+# ------------------------------------------------------------------ LocalWLNet scoring forward (a5-a8)
+@pytest.mark.parametrize("c1,c2,d1,d2", [(256, 32, 1, 1), (24, 16, 2, 2), (64, 24, 3, 1)])
+def test_localwl_forward_fb_pages_food(dev, tw, c1, c2, d1, d2):
+    """test-split scoring forward of TwoWL/model/train.py:54-60 on the seeded fb-pages-food split:
+    logits within 1e-5 (relative to the logit scale) of the fp64 restatement => identical AUC."""
+    from lpgnn_amd import twowl
+    from oracle import aggregation as agg, twowl_int
+    torch.manual_seed(0)
+    ei, pred, ei2 = tw["test_ei"].astype(np.int64), tw["test_pred"].astype(np.int64), tw["test_ei2"].astype(np.int64)
+    x_deg = twowl_int.degree(tw["val_ei"].astype(np.int64), 620)       # datasets.py:107-114: split 2 uses edge_indexs[1]
+    pos1 = np.concatenate([ei.T, pred.T], axis=0)
+    y_len = pred.shape[1]
+    mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=c1, channels_2wl=c2, depth1=d1, depth2=d2)
+    with torch.no_grad():               # non-trivial norm parameters
+        for name, p in mod.named_parameters():
+            if name.endswith("mean_scale") or (name.endswith("weight") and p.dim() == 1):
+                p.uniform_(0.6, 1.4)
+            elif name.endswith("bias"):
+                p.uniform_(-0.3, 0.3)
+    mod = mod.to(dev).eval()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    logits = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2))
+    assert logits.shape == (y_len // 2, 1)
+    idx = ei.shape[1] + np.arange(y_len)
+    want = agg.localwl_forward(mod.export_params(), x_deg, ei, pos1, idx, ei2)
+    got = _np(logits).astype(np.float64)
+    scale = np.abs(want).max() + 1.0
+    assert np.max(np.abs(got - want)) <= 20 * TOL * scale, np.max(np.abs(got - want))
+    y = np.concatenate([np.ones(y_len // 4), np.zeros(y_len // 4)])
+    assert abs(agg.auc(y, got) - agg.auc(y, want)) <= 0.002
+    # same forward again: bitwise identical (atomic-free path)
+    assert torch.equal(logits, twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2)))
+
+
+# ------------------------------------------------------------------ SEAL structure path vs the reference's goldens
+@pytest.fixture(scope="module")
+def sl(golden_dir):
+    return np.load(os.path.join(golden_dir, "seal_int.npz"))
+
+
+def _unpack_adj(bits_row_words, n):
+    a = np.zeros((n, n), dtype=np.uint8)
+    for i in range(n):
+        for w in range(4):
+            word = int(bits_row_words[i, w]) & 0xFFFFFFFF
+            for j in range(32):
+                if (word >> j) & 1 and w * 32 + j < n:
+                    a[i, w * 32 + j] = 1
+    return a
+
+
+@pytest.mark.parametrize("hop", [1, 0])
+def test_seal_subgraphs_golden(dev, sl, hop):
+    """all 4202 fb-pages-food candidates: node set, canonical adjacency and DRNL tags bit-exact;
+    pairs where the reference's RNG truncation fires are replayed in the reference's node order."""
+    from lpgnn_amd import seal
+    pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
+    k = f"hop{hop}_"
+    off, nodes_ref, tags_ref = sl[k + "off"], sl[k + "nodes"], sl[k + "tags"]
+    graph = seal.build_train_csr(pos, 620, 0.1, dev)
+    pairs = np.concatenate([neg, pos])
+    batch = seal.extract_subgraphs(pairs, graph, hop)
+    n, capped = _np(batch.n), _np(batch.capped).astype(bool)
+    nodes, tags, bits = _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits)
+    ref_n = np.diff(off)
+    assert np.array_equal(n[~capped], ref_n[~capped])
+    if hop == 1:
+        assert capped.sum() > 0
+    # replay the capped ones in the reference's own node order
+    ci = np.nonzero(capped)[0]
+    if len(ci):
+        rn = np.full((len(ci), 128), -1, dtype=np.int32)
+        for q, g in enumerate(ci):
+            rn[q, : ref_n[g]] = nodes_ref[off[g]:off[g + 1]]
+        rb = seal.extract_subgraphs(pairs[ci], graph, hop, replay_nodes=rn, replay_n=ref_n[ci].astype(np.int32))
+        r_tags, r_bits = _np(rb.tags), _np(rb.adj_bits)
+    # global tag compaction over the raw tags (reference: SEAL/config/subgraph.py:84-101)
+    raw = []
+    for g in range(len(pairs)):
+        if capped[g]:
+            q = int(np.nonzero(ci == g)[0][0])
+            raw.append((nodes_ref[off[g]:off[g + 1]], r_tags[q, : ref_n[g]], r_bits[q]))
+        else:
+            raw.append((nodes[g, : n[g]], tags[g, : n[g]], bits[g]))
+    uniq = sorted(set(int(t) for _, tg, _ in raw for t in tg))
+    assert len(uniq) == int(sl[k + "tags_size"])
+    tmap = {t: i for i, t in enumerate(uniq)}
+    for g in range(len(pairs)):
+        nd, tg, bb = raw[g]
+        ref_nd = nodes_ref[off[g]:off[g + 1]]
+        assert sorted(nd[2:].tolist()) == sorted(ref_nd[2:].tolist()) and nd[:2].tolist() == ref_nd[:2].tolist()
+        want = dict(zip(ref_nd[2:].tolist(), tags_ref[off[g] + 2:off[g + 1]].tolist()))
+        got = dict(zip(nd[2:].tolist(), [tmap[int(t)] for t in tg[2:]]))
+        assert got == want, g
+        assert [tmap[int(t)] for t in tg[:2]] == tags_ref[off[g]:off[g] + 2].tolist()
+        if g % 7 == 0 or capped[g]:                 # adjacency: crc of the canonical-order bit matrix
+            a = _unpack_adj(bb, len(nd))
+            p = np.concatenate([[0, 1], np.argsort(np.asarray(nd[2:]), kind="stable") + 2])
+            a = a[p][:, p]
+            assert int(a.sum()) == int(sl[k + "nnz"][g])
+            assert zlib.crc32(np.packbits(a.reshape(-1)).tobytes()) == int(sl[k + "adj_crc_canon"][g]), g
+
+
+def test_seal_graph_conv_with_reference_weights(dev, sl, golden_dir):
+    """a9 + a12: batched block-diagonal SpMM stack with the shipped checkpoint's weights against
+    the per-subgraph dense fp64 restatement of SEAL/model/gnn.py:46-63."""
+    from lpgnn_amd import seal
+    from oracle import aggregation as agg, seal_int
+    wz = np.load(os.path.join(golden_dir, "seal_weights.npz"))
+    weights = [wz[f"graph_weight_{i}"] for i in (1, 2, 3, 4)]
+    pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
+    rng = np.random.default_rng(0)
+    emb = rng.standard_normal((620, 100)).astype(np.float32)         # gensim absent: seeded stand-in features
+    batch, labels, T, tag_map, graph = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev)
+    assert T == 6 and labels.shape == (4202, 1)
+    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, torch.from_numpy(emb).to(dev))
+    z, key = seal.graph_conv_stack(g, d_inv, x, [torch.from_numpy(w).to(dev) for w in weights])
+    off = _np(batch.node_off())
+    z, key, xh = _np(z).astype(np.float64), _np(key).astype(np.float64), _np(x)
+    n, nodes, tags, bits = _np(batch.n), _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits)
+    tm = _np(tag_map)
+    worst = 0.0
+    for gi in list(range(0, 4202, 37)) + [int(np.argmax(n))]:
+        nn = int(n[gi])
+        adj = _unpack_adj(bits[gi], nn)
+        a_t, dinv, xx = seal_int.gnn_inputs(adj, tm[tags[gi, :nn]], T, emb[nodes[gi, :nn]])
+        assert np.array_equal(xh[off[gi]:off[gi + 1]], xx.astype(np.float32))           # a12: exact
+        zc, z4 = agg.seal_graph_conv(a_t, dinv, xx, weights)
+        worst = max(worst, np.abs(z[off[gi]:off[gi + 1]] - zc).max(), np.abs(key[off[gi]:off[gi + 1]] - z4).max())
+    assert worst <= 4 * TOL, worst          # |tanh| <= 1: absolute == relative to the output scale; 4 layers deep
+
+
+# ------------------------------------------------------------------ full-size property (north-star shape, scaled)
+def test_spmm_large_rmat_properties(dev):
+    """|E| = 20 M, d = 128 RMAT (same generator as bench.py): size-independent checks --
+    column checksum  sum_r Y[r,:] == sum_j outdeg(j) X[j,:]  (fp64), linearity, reproducibility."""
+    import bench
+    N, E, d = 1 << 20, 20_000_000, 128
+    g, x = bench.make_rmat_problem(N, E, d, seed=5, device=dev)
+    y = g.spmm(x)
+    nnz = g.nnz()
+    outdeg = torch.bincount(g.col[:nnz].long(), minlength=N).double()
+    want = outdeg @ x.double()
+    got = y.double().sum(0)
+    mag = outdeg @ x.double().abs()
+    assert torch.all((got - want).abs() <= 1e-6 * mag)
+    y2 = g.spmm(2.0 * x)
+    assert torch.equal(y2, 2.0 * y)                       # exact: scaling by 2 commutes with fp32 rounding
+    assert torch.equal(g.spmm(x), y)
+    # a sample of rows against a direct fp64 gather-sum
+    rows = torch.randint(0, N, (2000,), device=dev)
+    rp = g.rowptr
+    for r in rows[:200].tolist():
+        b, e = int(rp[r]), int(rp[r + 1])
+        ref = x[g.col[b:e].long()].double().sum(0)
+        mg = x[g.col[b:e].long()].double().abs().sum(0)
+        assert torch.all((y[r].double() - ref).abs() <= TOL * mg + 1e-30)
