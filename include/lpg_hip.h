@@ -43,8 +43,9 @@ extern "C" {
 
 const char* lpg_last_error(void);
 int lpg_abi_version(void);
-/* edges per work chunk of the chunked SpMM (needed to size workspaces on the host) */
-int lpg_spmm_chunk_edges(void);
+/* edges per work chunk the chunked SpMM uses for a graph of capacity e_cap (64..512; tests use it
+ * to place rows on chunk borders) */
+int lpg_spmm_chunk_edges(int64_t e_cap);
 
 /* ---------------------------------------------------------------- scatter_add (K1, K2)
  * torch_scatter.scatter_add(src, index, dim=0, out=None, dim_size=N)   [TwoWL/utils.py:5,10]

@@ -19,12 +19,46 @@
 //    kernel writes act(bias) there.
 //  * The actual nnz is read from rowptr[N] on the device: launch geometry depends only on the
 //    capacity, so no host sync is needed between graph build and SpMM.
+#include <stdlib.h>
+
 #include "lpg_common.hpp"
 
 namespace {
 using namespace lpg;
 
-constexpr int kChunk = 256;  // edges per group chunk
+constexpr int kDefaultChunk = 512;  // edges per group chunk
+
+// Tuning hooks (profiles/sweep_spmm.py): LPG_SPMM_CHUNK = edges per chunk (multiple of 64),
+// LPG_SPMM_LDS = bytes of LDS reserved per workgroup (occupancy limiter; -1/unset = automatic),
+// LPG_SPMM_BLOCK = threads per workgroup, LPG_SPMM_MODE = 2 gather-only (debug upper bound: no row
+// flushes, results are WRONG).  Defaults are the tuned values.
+struct Tune {
+  int chunk, mode, lds, block;
+  Tune() {
+    const char* c = getenv("LPG_SPMM_CHUNK");
+    const char* m = getenv("LPG_SPMM_MODE");
+    chunk = c ? atoi(c) : 0;           // 0 = automatic (chunk_for)
+    if (chunk < 0 || chunk % 64 != 0) chunk = 0;
+    mode = m ? atoi(m) : 0;
+    const char* l = getenv("LPG_SPMM_LDS");
+    lds = l ? atoi(l) : -1;   // -1 = automatic
+    const char* bb = getenv("LPG_SPMM_BLOCK");
+    block = bb ? atoi(bb) : kBlock;
+    if (block != 64 && block != 128 && block != 256) block = kBlock;
+  }
+};
+inline Tune tune() { return Tune(); }   // re-read per call: lets one process sweep variants
+
+// Edges per chunk: 512 on big graphs (flat between 256 and 2048, sweep_notes.md); small graphs get
+// smaller chunks so that a 70 K-edge tuple graph still spreads over ~1000 groups instead of
+// running 512 dependent gathers in a handful of waves (243 us -> latency of 8 batches).
+inline int chunk_for(int64_t e_cap) {
+  const int forced = tune().chunk;
+  if (forced) return forced;
+  int c = 64;
+  while (c < kDefaultChunk && static_cast<int64_t>(c) * 2 * 4096 <= e_cap) c *= 2;
+  return c;
+}
 
 struct SpmmArgs {
   const int64_t* rowptr;
@@ -41,6 +75,7 @@ struct SpmmArgs {
   int act;
   float* carry;   // [2 * n_chunks_cap][dpad]
   int64_t dpad;
+  int chunk;      // edges per chunk
 };
 
 // ---- 16-byte (or scalar) row pieces ---------------------------------------------------------
@@ -116,28 +151,33 @@ __device__ __forceinline__ void carry_add(const float* p, float (&acc)[VEC]) {
   }
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool EPI = true>
 __device__ __forceinline__ void store_out(const SpmmArgs& a, int64_t row, int64_t c0, const float (&acc)[VEC]) {
-  float o[VEC];
-  const float rs = a.row_scale ? a.row_scale[row] : 1.f;
+  if constexpr (!EPI) {      // plain Y = A @ X: no row scale, bias or activation
+    Piece<T, VEC>::store(static_cast<T*>(a.y) + row * a.ldy + c0, acc);
+  } else {
+    float o[VEC];
+    const float rs = a.row_scale ? a.row_scale[row] : 1.f;
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    float v = acc[i];
-    if (a.row_scale) v *= rs;
-    if (a.bias) v += a.bias[c0 + i];
-    o[i] = apply_act(v, a.act);
+    for (int i = 0; i < VEC; ++i) {
+      float v = acc[i];
+      if (a.row_scale) v *= rs;
+      if (a.bias) v += a.bias[c0 + i];
+      o[i] = apply_act(v, a.act);
+    }
+    Piece<T, VEC>::store(static_cast<T*>(a.y) + row * a.ldy + c0, o);
   }
-  Piece<T, VEC>::store(static_cast<T*>(a.y) + row * a.ldy + c0, o);
 }
 
 // ---- main kernel -----------------------------------------------------------------------------
-template <typename T, int VEC, int G, bool WEIGHTED>
+template <typename T, int VEC, int G, bool WEIGHTED, bool EPI, int UREQ, int MODE>
 __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
   constexpr int GPW = kWave / G;            // groups (chunks) per wave
-  constexpr int U = G < 8 ? G : 8;          // row gathers in flight per group step
+  constexpr int U = G < UREQ ? G : UREQ;    // row gathers in flight per group step
+  const int kChunk = a.chunk;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
-  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t E = a.rowptr[a.N];
   if (wave * GPW * kChunk >= E) return;     // wave-uniform
   const int64_t chunk = wave * GPW + lane / G;
@@ -162,6 +202,13 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
   float* carry0 = a.carry + (2 * chunk) * a.dpad + c0;
 
+  // REP: bit pattern selecting steps [0, U) of every group in the 64-bit ballot
+  unsigned long long rep = 0;
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) rep |= ((U >= 64 ? ~0ull : ((1ull << U) - 1ull))) << (gi * G);
+  const bool wave_full = __all(n_e == kChunk);      // only the last wave has a ragged tail
+  const int gshift = lane & ~(G - 1);
+
 #pragma unroll 1
   for (int base = 0; base < kChunk; base += G) {
     if (!__any(base < n_e)) break;
@@ -170,7 +217,9 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
     const int c = in ? a.col[e] : 0;
     const int r = in ? a.rowid[e] : -1;
     const int rn = (in && e + 1 < E) ? a.rowid[e + 1] : -2;
-    const int fl = (in && r != rn) ? 1 : 0;
+    const bool fl = in && r != rn;                   // a row ends at this lane's edge
+    const unsigned long long fmask = __ballot(fl);   // wave-uniform: one bit per (group, step)
+    const unsigned long long mym = fmask >> gshift;  // this group's bits at [0, G)
     float w = 0.f;
     if constexpr (WEIGHTED) w = in ? a.val[e] : 0.f;
 
@@ -182,31 +231,48 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
         const int cj = __shfl(c, j0 + u, G);
         raw[u] = Piece<T, VEC>::load(xb + static_cast<int64_t>(cj) * a.ldx);
       }
+      const bool any_flush = (fmask & (rep << j0)) != 0ull;      // scalar test
+      if (MODE == 2 || (wave_full && !any_flush)) {
+        // fast path (most sub-batches): no row ends here in any group -> straight accumulate
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool ok = base + j0 + u < n_e;
-        const int fj = __shfl(fl, j0 + u, G);
-        const int rj = __shfl(r, j0 + u, G);
-        float v[VEC];
-        Piece<T, VEC>::widen(raw[u], v);
-        if constexpr (WEIGHTED) {
-          const float wj = __shfl(w, j0 + u, G);   // 0 for edges past the chunk end
+        for (int u = 0; u < U; ++u) {
+          float v[VEC];
+          Piece<T, VEC>::widen(raw[u], v);
+          if constexpr (WEIGHTED) {
+            const float wj = __shfl(w, j0 + u, G);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wj, ok ? v[i] : 0.f, acc[i]);
-        } else {
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wj, v[i], acc[i]);
+          } else {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] += ok ? v[i] : 0.f;
-        }
-        if (fj) {                                   // a row ends at this edge
-          if (lane_on) {
-            if (first_seg && open_left)
-              carry_store<VEC>(carry0, acc);        // last piece of a row begun in an earlier chunk
-            else
-              store_out<T, VEC>(a, rj, c0, acc);
+            for (int i = 0; i < VEC; ++i) acc[i] += v[i];
           }
+        }
+      } else {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-          first_seg = false;
+        for (int u = 0; u < U; ++u) {
+          const bool ok = base + j0 + u < n_e;
+          float v[VEC];
+          Piece<T, VEC>::widen(raw[u], v);
+          if constexpr (WEIGHTED) {
+            const float wj = __shfl(w, j0 + u, G);   // 0 for edges past the chunk end
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wj, ok ? v[i] : 0.f, acc[i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += ok ? v[i] : 0.f;
+          }
+          if ((mym >> (j0 + u)) & 1ull) {            // a row ends at this edge (group-uniform)
+            const int rj = __shfl(r, j0 + u, G);
+            if (lane_on) {
+              if (first_seg && open_left)
+                carry_store<VEC>(carry0, acc);        // last piece of a row begun in an earlier chunk
+              else
+                store_out<T, VEC, EPI>(a, rj, c0, acc);
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            first_seg = false;
+          }
         }
       }
     }
@@ -220,7 +286,8 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
   constexpr int GPW = kWave / G;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
-  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int kChunk = a.chunk;
   const int64_t E = a.rowptr[a.N];
   if (wave * GPW * kChunk >= E) return;
   const int64_t chunk = wave * GPW + lane / G;
@@ -256,32 +323,52 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
 }
 
 // ---- rows without edges: act(bias) -------------------------------------------------------------
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void spmm_empty_rows_kernel(const SpmmArgs a) {
-  const int64_t total = static_cast<int64_t>(*a.n_empty) * a.d;
+  const int64_t dv = a.d / VEC;
+  const int64_t total = static_cast<int64_t>(*a.n_empty) * dv;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
-    const int64_t i = t / a.d, c = t - i * a.d;
+    const int64_t i = t / dv, c = (t - i * dv) * VEC;
     const int64_t row = a.empty_rows[i];
-    float acc[1] = {0.f};
-    store_out<T, 1>(a, row, c, acc);
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    store_out<T, VEC>(a, row, c, acc);
   }
 }
 
 template <typename T, int VEC, int G>
 int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
   constexpr int GPW = kWave / G;
+  const int kChunk = a.chunk;
   const int64_t n_chunks = ceil_div(e_cap, kChunk);
+  const Tune tn = tune();
+  // Occupancy limiter.  On big graphs the row gather runs ~9 % FASTER with ONE workgroup (4 waves,
+  // 8 x 1 KiB gathers each = 32 KiB in flight) per CU than at full occupancy (256 KiB in flight):
+  // measured 8.28 vs 9.27 ms on |E| = 100 M, d = 128 (profiles/r01/sweep_notes.md).  Reserving more
+  // than half of the CU's 160 KiB LDS per workgroup admits exactly one.  Small graphs are latency
+  // bound and keep the default.
+  int lds = tn.lds;
+  if (lds < 0) lds = (e_cap >= (int64_t(1) << 20) && G * VEC * sizeof(T) >= 256) ? 90000 : 0;
   const int64_t n_waves = ceil_div(n_chunks, GPW);
-  const int64_t n_blocks = ceil_div(n_waves, kBlock / kWave);
+  const int64_t n_blocks = ceil_div(n_waves, tn.block / kWave);
+  const dim3 blk(tn.block);
   const int64_t tiles = ceil_div(a.d, G * VEC);
   LPG_REQUIRE(n_blocks < (int64_t(1) << 31) && tiles < 65536, "csr_spmm: grid too large");
   dim3 grid(static_cast<unsigned>(n_blocks), static_cast<unsigned>(tiles));
-  if (a.val)
-    hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, true>), grid, dim3(kBlock), 0, st, a);
-  else
-    hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, false>), grid, dim3(kBlock), 0, st, a);
-  hipLaunchKernelGGL((spmm_fixup_kernel<T, VEC, G>), grid, dim3(kBlock), 0, st, a);
+  const bool epi = a.row_scale || a.bias || a.act != LPG_ACT_NONE;
+#define LPG_LAUNCH_MAIN(W, EP, MD) \
+  hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, W, EP, 8, MD>), grid, blk, lds, st, a)
+  if (tn.mode == 2 && !a.val && !epi) {
+    LPG_LAUNCH_MAIN(false, false, 2);          // debug: gather-only upper bound (wrong results)
+  } else if (a.val) {
+    if (epi) LPG_LAUNCH_MAIN(true, true, 0); else LPG_LAUNCH_MAIN(true, false, 0);
+  } else {
+    if (epi) LPG_LAUNCH_MAIN(false, true, 0); else LPG_LAUNCH_MAIN(false, false, 0);
+  }
+#undef LPG_LAUNCH_MAIN
+  hipLaunchKernelGGL((spmm_fixup_kernel<T, VEC, G>), grid, blk, 0, st, a);
   return LPG_OK;
 }
 
@@ -323,22 +410,27 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
   a.row_scale = row_scale; a.bias = bias; a.act = act;
   a.carry = static_cast<float*>(workspace);
   a.dpad = align_up(d, 4);
+  a.chunk = chunk_for(e_cap);
   if (e_cap > 0) {
     const bool wide = d % WIDE == 0 && ldx % WIDE == 0 && ldy % WIDE == 0 &&
                       reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
     const int rc = wide ? launch_vec<T, WIDE>(a, e_cap, st) : launch_vec<T, 1>(a, e_cap, st);
     if (rc != LPG_OK) return rc;
   }
-  hipLaunchKernelGGL((spmm_empty_rows_kernel<T>), dim3(grid_for(N * (d < 64 ? d : 64))), dim3(kBlock), 0, st, a);
+  const bool wide_out = d % WIDE == 0 && ldy % WIDE == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+  if (wide_out)
+    hipLaunchKernelGGL((spmm_empty_rows_kernel<T, WIDE>), dim3(grid_for(N * (d < 64 ? d : 64) / WIDE)), dim3(kBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL((spmm_empty_rows_kernel<T, 1>), dim3(grid_for(N * (d < 64 ? d : 64))), dim3(kBlock), 0, st, a);
   return check_launch("csr_spmm");
 }
 }  // namespace
 
-LPG_EXPORT int lpg_spmm_chunk_edges(void) { return kChunk; }
+LPG_EXPORT int lpg_spmm_chunk_edges(int64_t e_cap) { return chunk_for(e_cap); }
 
 LPG_EXPORT int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d) {
   if (e_cap < 0 || d < 1) return LPG_E_INVALID;
-  return 2 * lpg::ceil_div(e_cap, kChunk) * lpg::align_up(d, 4) * 4 + 256;
+  return 2 * lpg::ceil_div(e_cap, chunk_for(e_cap)) * lpg::align_up(d, 4) * 4 + 256;
 }
 
 LPG_EXPORT int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,

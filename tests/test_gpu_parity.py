@@ -197,7 +197,9 @@ def test_spmm_chunk_border_exhaustive(dev):
     """rows whose edge runs start / end exactly on, one before and one after chunk borders."""
     import lpgnn_amd
     from oracle import aggregation as agg
-    T = lpgnn_amd.load_library().lpg_spmm_chunk_edges()
+    lens0 = [63, 1, 64, 65, 0, 128, 1, 1, 62, 197, 0, 0, 7]
+    T = lpgnn_amd.load_library().lpg_spmm_chunk_edges(sum(lens0))
+    assert T == 64
     rng = np.random.default_rng(3)
     lens = [T - 1, 1, T, T + 1, 0, 2 * T, 1, 1, T - 2, 3 * T + 5, 0, 0, 7]
     n_rows, n_cols, d = len(lens), 97, 32
