@@ -43,7 +43,7 @@ extern "C" {
 
 const char* lpg_last_error(void);
 int lpg_abi_version(void);
-/* edges per work chunk the chunked SpMM uses for a graph of capacity e_cap (64..512; tests use it
+/* edges per work chunk the chunked SpMM uses for a graph of capacity e_cap (16..512; tests use it
  * to place rows on chunk borders) */
 int lpg_spmm_chunk_edges(int64_t e_cap);
 
@@ -66,10 +66,13 @@ int lpg_scatter_add_f32(const float* src, const int64_t* index, int64_t E, int64
  * loop per node is appended after the row's other edges (weight = the node's last existing loop
  * weight if `val` is given, else fill 1).  Capacity of col_out/val_out/perm_out: E (+ N with
  * self loops).  The number of stored edges is rowptr[N] (device value).
- * perm_out[k] = original edge id of CSR slot k (>= E for appended loops); may be NULL. */
+ * perm_out[k] = original edge id of CSR slot k (>= E for appended loops); may be NULL.
+ * flip: bit 0 -> source ids are read as id^1, bit 1 -> destination ids as id^1: the two tuple-graph
+ * orientations of TwoWL reverse() (edge = (flip(e0), e1), edge_r = (e0, flip(e1)),
+ * TwoWL/utils.py:71-78) are built straight from ei2 without materialising them. */
 int64_t lpg_coo_to_csr_bytes(int64_t E, int64_t N, int gcn_self_loops);
 int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const float* val, int64_t E,
-                   int64_t n_rows, int64_t n_cols, int gcn_self_loops,
+                   int64_t n_rows, int64_t n_cols, int gcn_self_loops, int flip,
                    int64_t* rowptr, int32_t* col_out, float* val_out, int32_t* perm_out,
                    void* workspace, int64_t workspace_bytes, int32_t* err_flag, void* stream);
 
@@ -96,18 +99,20 @@ int lpg_csr_plan_build(const int64_t* rowptr, const int32_t* col, int64_t N, int
  * val == NULL: all ones.  row_scale / bias may be NULL.  ldx/ldy = row strides in elements.
  * Atomic-free and bitwise reproducible: edges are cut into fixed chunks, rows that straddle
  * chunks are finished by a second kernel that adds the partials in chunk order.
- * bf16 variant: x, y are bfloat16 (uint16 bit patterns), accumulation in fp32. */
+ * bf16 variant: x, y are bfloat16 (uint16 bit patterns), accumulation in fp32.
+ * n_empty_hint: number of rows without edges if the caller knows it (0 skips the empty-row
+ * launch), -1 = unknown (read from the plan on the device). */
 int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d);
 int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col,
                      const float* val, const float* x, int64_t ldx, float* y, int64_t ldy,
                      int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
-                     const float* bias, int act, void* workspace, int64_t workspace_bytes,
-                     void* stream);
+                     const float* bias, int act, int64_t n_empty_hint, void* workspace,
+                     int64_t workspace_bytes, void* stream);
 int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* col,
                       const float* val, const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy,
                       int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
-                      const float* bias, int act, void* workspace, int64_t workspace_bytes,
-                      void* stream);
+                      const float* bias, int act, int64_t n_empty_hint, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- dense feature linear (K5)
  * Y[n,m] = X[n,k] @ W^T (+ bias), W is [m,k] (nn.Linear / GCNConv.lin layout) or, with

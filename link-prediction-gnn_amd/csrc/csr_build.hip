@@ -58,14 +58,17 @@ CooWs carve(void* ws, int64_t E, int64_t N, int loops) {
 __global__ __launch_bounds__(kBlock) void coo_keys_kernel(const int64_t* __restrict__ src,
                                                           const int64_t* __restrict__ dst,
                                                           const float* __restrict__ val, int64_t E, int64_t n_rows,
-                                                          int64_t n_cols, int loops, uint64_t* __restrict__ keys,
+                                                          int64_t n_cols, int loops, int flip,
+                                                          uint64_t* __restrict__ keys,
                                                           int32_t* __restrict__ loop_last, int32_t* err_flag) {
   const int64_t M = E + (loops ? n_rows : 0);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < M; e += stride) {
     uint64_t row;
     if (e < E) {
-      const int64_t s = src[e], t = dst[e];
+      int64_t s = src[e], t = dst[e];
+      if (flip & 1) s ^= 1;            // TwoWL reverse(): partner-direction tuple id (utils.py:71-78)
+      if (flip & 2) t ^= 1;
       if (s < 0 || s >= n_cols || t < 0 || t >= n_rows) {
         flag_error(err_flag, LPG_F_INDEX_RANGE);
         row = static_cast<uint64_t>(n_rows);  // dropped bucket
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void rowptr_from_sorted_kernel(const uint64
 }
 
 __global__ __launch_bounds__(kBlock) void coo_gather_kernel(const uint64_t* __restrict__ keys, int64_t M, int64_t E,
-                                                            const int64_t* __restrict__ src,
+                                                            const int64_t* __restrict__ src, int flip,
                                                             const float* __restrict__ val,
                                                             const int32_t* __restrict__ loop_last,
                                                             int32_t* __restrict__ col_out, float* __restrict__ val_out,
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void coo_gather_kernel(const uint64_t* __re
     int32_t c;
     float w = 1.f;
     if (e < E) {
-      c = static_cast<int32_t>(src[e]);
+      c = static_cast<int32_t>((flip & 1) ? (src[e] ^ 1) : src[e]);
       if (val) w = val[e];
     } else {
       c = static_cast<int32_t>(e - E);
@@ -191,7 +194,7 @@ LPG_EXPORT int64_t lpg_coo_to_csr_bytes(int64_t E, int64_t N, int gcn_self_loops
 }
 
 LPG_EXPORT int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const float* val, int64_t E, int64_t n_rows,
-                              int64_t n_cols, int gcn_self_loops, int64_t* rowptr, int32_t* col_out, float* val_out,
+                              int64_t n_cols, int gcn_self_loops, int flip, int64_t* rowptr, int32_t* col_out, float* val_out,
                               int32_t* perm_out, void* workspace, int64_t workspace_bytes, int32_t* err_flag,
                               void* stream) {
   LPG_REQUIRE(E >= 0 && n_rows >= 0 && n_cols >= 0, "coo_to_csr: negative size");
@@ -209,7 +212,7 @@ LPG_EXPORT int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const floa
   if (gcn_self_loops && val) LPG_HIP(hipMemsetAsync(w.loop_last, 0xff, static_cast<size_t>(n_rows + 1) * 4, st));
   if (M > 0) {
     hipLaunchKernelGGL(coo_keys_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, src, dst, val, E, n_rows, n_cols,
-                       gcn_self_loops, w.keys_in, w.loop_last, err_flag);
+                       gcn_self_loops, flip, w.keys_in, w.loop_last, err_flag);
     size_t tmp = w.sort_tmp_bytes;
     LPG_HIP(rocprim::radix_sort_keys(w.sort_tmp, tmp, w.keys_in, w.keys_out, static_cast<size_t>(M), 0u,
                                      32 + bits_for(n_rows), st, false));
@@ -217,7 +220,7 @@ LPG_EXPORT int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const floa
   hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(grid_for(M + 1)), dim3(kBlock), 0, st, w.keys_out, M, n_rows,
                      rowptr);
   if (M > 0)
-    hipLaunchKernelGGL(coo_gather_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, w.keys_out, M, E, src, val,
+    hipLaunchKernelGGL(coo_gather_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, w.keys_out, M, E, src, flip, val,
                        w.loop_last, col_out, val_out, perm_out);
   return check_launch("coo_to_csr");
 }

@@ -32,8 +32,8 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_f32_kernel(const float* __
 
   for (int64_t k0 = 0; k0 < k; k0 += KT) {
     // X tile: each wave stages its own 32 rows, one 256-byte row segment per instruction
-#pragma unroll 4
-    for (int it = 0; it < 32; ++it) {
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {          // 32 independent loads in flight: one latency, not eight
       const int64_t r = row0 + it, kk = k0 + lane;
       Xs[wave][it][lane] = (r < n && kk < k) ? x[r * ldx + kk] : 0.f;
     }

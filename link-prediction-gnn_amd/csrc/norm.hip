@@ -47,27 +47,37 @@ __global__ __launch_bounds__(kBlock) void gn_partial_kernel(const float* __restr
   }
 }
 
+// one wave per column: lanes stride the per-block partials, xor-shuffle tree (fixed order)
 __global__ __launch_bounds__(kBlock) void gn_finalize_kernel(const double* __restrict__ part, int nblocks, int64_t n,
                                                              int64_t d, const float* __restrict__ weight,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ mean_scale, float eps,
                                                              float* __restrict__ stats) {
-  for (int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; c < d;
-       c += static_cast<int64_t>(gridDim.x) * kBlock) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  for (int64_t c = wave; c < d; c += nwaves) {
     double s = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
       s += part[(static_cast<int64_t>(b) * 2 + 0) * d + c];
       s2 += part[(static_cast<int64_t>(b) * 2 + 1) * d + c];
     }
-    const double mean = s / static_cast<double>(n);
-    const double ex2 = s2 / static_cast<double>(n);
-    const double ms = mean_scale ? static_cast<double>(mean_scale[c]) : 1.0;
-    double var = ex2 - mean * mean * ms * (2.0 - ms);
-    if (var < 0.0) var = 0.0;
-    const double inv = 1.0 / sqrt(var + static_cast<double>(eps));
-    stats[c] = static_cast<float>(mean * ms);
-    stats[d + c] = static_cast<float>((weight ? static_cast<double>(weight[c]) : 1.0) * inv);
-    stats[2 * d + c] = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (lane == 0) {
+      const double mean = s / static_cast<double>(n);
+      const double ex2 = s2 / static_cast<double>(n);
+      const double ms = mean_scale ? static_cast<double>(mean_scale[c]) : 1.0;
+      double var = ex2 - mean * mean * ms * (2.0 - ms);
+      if (var < 0.0) var = 0.0;
+      const double inv = 1.0 / sqrt(var + static_cast<double>(eps));
+      stats[c] = static_cast<float>(mean * ms);
+      stats[d + c] = static_cast<float>((weight ? static_cast<double>(weight[c]) : 1.0) * inv);
+      stats[2 * d + c] = bias ? bias[c] : 0.f;
+    }
   }
 }
 
@@ -139,8 +149,8 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
   int dp = 1;
   while (dp < d && dp < kBlock) dp <<= 1;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nb), dim3(kBlock), 0, st, x, n, d, rpb, dp, part);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(static_cast<int>(ceil_div(d, kBlock))), dim3(kBlock), 0, st, part, nb, n,
-                     d, weight, bias, mean_scale, eps, stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(grid_for(d * 64)), dim3(kBlock), 0, st, part, nb, n, d, weight, bias,
+                     mean_scale, eps, stats);
   const bool wide = d % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
                     (!add_to || reinterpret_cast<uintptr_t>(add_to) % 16 == 0);
   if (wide)

@@ -38,7 +38,7 @@ struct Tune {
     const char* c = getenv("LPG_SPMM_CHUNK");
     const char* m = getenv("LPG_SPMM_MODE");
     chunk = c ? atoi(c) : 0;           // 0 = automatic (chunk_for)
-    if (chunk < 0 || chunk % 64 != 0) chunk = 0;
+    if (chunk < 0 || chunk % 16 != 0) chunk = 0;
     mode = m ? atoi(m) : 0;
     const char* l = getenv("LPG_SPMM_LDS");
     lds = l ? atoi(l) : -1;   // -1 = automatic
@@ -50,12 +50,12 @@ struct Tune {
 inline Tune tune() { return Tune(); }   // re-read per call: lets one process sweep variants
 
 // Edges per chunk: 512 on big graphs (flat between 256 and 2048, sweep_notes.md); small graphs get
-// smaller chunks so that a 70 K-edge tuple graph still spreads over ~1000 groups instead of
-// running 512 dependent gathers in a handful of waves (243 us -> latency of 8 batches).
+// smaller chunks (down to 16) so that a 70 K-edge tuple graph still spreads over thousands of
+// groups instead of running 512 dependent gathers in a handful of waves (243 us -> ~10 us).
 inline int chunk_for(int64_t e_cap) {
   const int forced = tune().chunk;
   if (forced) return forced;
-  int c = 64;
+  int c = 16;
   while (c < kDefaultChunk && static_cast<int64_t>(c) * 2 * 4096 <= e_cap) c *= 2;
   return c;
 }
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
 
 #pragma unroll 1
     for (int j0 = 0; j0 < G; j0 += U) {
+      if (!__any(base + j0 < n_e)) break;            // chunk shorter than the group width
       typename Piece<T, VEC>::Raw raw[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -387,7 +388,8 @@ int launch_vec(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
 template <typename T, int WIDE>
 int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val, const T* x,
                int64_t ldx, T* y, int64_t ldy, int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
-               const float* bias, int act, void* workspace, int64_t workspace_bytes, void* stream) {
+               const float* bias, int act, int64_t n_empty_hint, void* workspace, int64_t workspace_bytes,
+               void* stream) {
   LPG_REQUIRE(N >= 0 && e_cap >= 0 && d >= 1, "csr_spmm: bad sizes N=%lld e_cap=%lld d=%lld", (long long)N,
               (long long)e_cap, (long long)d);
   if (N == 0) return LPG_OK;
@@ -417,6 +419,7 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
     const int rc = wide ? launch_vec<T, WIDE>(a, e_cap, st) : launch_vec<T, 1>(a, e_cap, st);
     if (rc != LPG_OK) return rc;
   }
+  if (n_empty_hint == 0) return check_launch("csr_spmm");
   const bool wide_out = d % WIDE == 0 && ldy % WIDE == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
   if (wide_out)
     hipLaunchKernelGGL((spmm_empty_rows_kernel<T, WIDE>), dim3(grid_for(N * (d < 64 ? d : 64) / WIDE)), dim3(kBlock), 0, st, a);
@@ -435,16 +438,16 @@ LPG_EXPORT int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d) {
 
 LPG_EXPORT int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,
                                 const float* x, int64_t ldx, float* y, int64_t ldy, int64_t N, int64_t e_cap,
-                                int64_t d, const float* row_scale, const float* bias, int act, void* workspace,
-                                int64_t workspace_bytes, void* stream) {
-  return spmm_entry<float, 4>(plan, rowptr, col, val, x, ldx, y, ldy, N, e_cap, d, row_scale, bias, act, workspace,
-                              workspace_bytes, stream);
+                                int64_t d, const float* row_scale, const float* bias, int act, int64_t n_empty_hint,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+  return spmm_entry<float, 4>(plan, rowptr, col, val, x, ldx, y, ldy, N, e_cap, d, row_scale, bias, act, n_empty_hint,
+                              workspace, workspace_bytes, stream);
 }
 
 LPG_EXPORT int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,
                                  const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t N, int64_t e_cap,
-                                 int64_t d, const float* row_scale, const float* bias, int act, void* workspace,
-                                 int64_t workspace_bytes, void* stream) {
+                                 int64_t d, const float* row_scale, const float* bias, int act, int64_t n_empty_hint,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
   return spmm_entry<uint16_t, 8>(plan, rowptr, col, val, x, ldx, y, ldy, N, e_cap, d, row_scale, bias, act,
-                                 workspace, workspace_bytes, stream);
+                                 n_empty_hint, workspace, workspace_bytes, stream);
 }

@@ -33,14 +33,14 @@ class _GraphCache:
         self.capacity = capacity
         self._d = OrderedDict()
 
-    def get(self, edge_index, edge_weight, n, gcn):
-        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), edge_index.device, n, gcn,
+    def get(self, edge_index, edge_weight, n, gcn, flip=0):
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), edge_index.device, n, gcn, flip,
                None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version))
         hit = self._d.get(key)
         if hit is not None:
             self._d.move_to_end(key)
             return hit[0]
-        g = _ops.CSRGraph.from_edge_index(edge_index, n, n, edge_weight=edge_weight, gcn_self_loops=gcn)
+        g = _ops.CSRGraph.from_edge_index(edge_index, n, n, edge_weight=edge_weight, gcn_self_loops=gcn, flip=flip)
         if gcn:
             g.gcn_normalize_()
         self._d[key] = (g, edge_index, edge_weight)
@@ -88,8 +88,12 @@ class GCNConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
     def forward(self, x, edge_index, edge_weight=None):
+        """edge_index: [2,E] int64 tensor (PyG), or a prebuilt gcn-normalised CSRGraph."""
         _forward_only(self)
-        g = graph_cache.get(edge_index, edge_weight, x.shape[0], True)
+        if isinstance(edge_index, _ops.CSRGraph):
+            g = edge_index
+        else:
+            g = graph_cache.get(edge_index, edge_weight, x.shape[0], True)
         h = self.lin(x)                                   # K5: H = X W^T on the fp32 matrix cores
         return g.spmm(h, bias=self.bias)                  # K3+K4: A_hat @ H + b, one fused kernel
 

@@ -50,7 +50,8 @@ def raise_if_flagged(device, what="index"):
 
 
 def maybe_check(device, what="index"):
-    if _CHECK:
+    # no host sync while a hipGraph is being captured: the flag is read after the replay instead
+    if _CHECK and not torch.cuda.is_current_stream_capturing():
         raise_if_flagged(device, what)
 
 
@@ -101,12 +102,14 @@ class CSRGraph:
         self.device = rowptr.device
         self._plan = None
         self._ws = {}
+        self.n_empty = -1          # rows without edges, once known on the host (0 skips a launch)
 
     # -- construction ----------------------------------------------------------------------
     @staticmethod
     def from_edge_index(edge_index, n_rows, n_cols=None, edge_weight=None, gcn_self_loops=False,
-                        keep_perm=False):
-        """edge_index [2,E] int64 (row 0 = source, row 1 = destination), PyG convention."""
+                        keep_perm=False, flip=0):
+        """edge_index [2,E] int64 (row 0 = source, row 1 = destination), PyG convention.
+        flip: bit 0 / bit 1 read source / destination ids as id^1 (TwoWL reverse())."""
         lib = _lib.load()
         _need_gpu(edge_index, edge_weight)
         n_cols = n_rows if n_cols is None else n_cols
@@ -124,12 +127,12 @@ class CSRGraph:
         nbytes = _lib.check(lib.lpg_coo_to_csr_bytes(E, n_rows, int(gcn_self_loops)), "coo_to_csr_bytes")
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         flag = err_flag(dev)
-        _lib.check(lib.lpg_coo_to_csr(_ptr(src), _ptr(dst), _ptr(w), E, n_rows, n_cols, int(gcn_self_loops),
+        _lib.check(lib.lpg_coo_to_csr(_ptr(src), _ptr(dst), _ptr(w), E, n_rows, n_cols, int(gcn_self_loops), int(flip),
                                       _ptr(rowptr), _ptr(col), _ptr(val), _ptr(perm), _ptr(ws), nbytes,
                                       _ptr(flag), _stream()), "coo_to_csr")
         g = CSRGraph(rowptr, col, val, n_rows, n_cols, e_cap, perm=perm)
         g._build_plan()
-        raise_if_flagged(dev, "edge_index")     # one sync per graph build
+        g._finish_build("edge_index")           # one sync per graph build
         return g
 
     @staticmethod
@@ -140,7 +143,7 @@ class CSRGraph:
         val = _c(val, torch.float32)
         g = CSRGraph(rowptr, col, val, rowptr.numel() - 1, n_cols, col.numel())
         g._build_plan()
-        raise_if_flagged(rowptr.device, "csr col/rowptr")
+        g._finish_build("csr col/rowptr")
         return g
 
     def _build_plan(self):
@@ -150,6 +153,11 @@ class CSRGraph:
         _lib.check(lib.lpg_csr_plan_build(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, self.e_cap,
                                           _ptr(self._plan), nbytes, _ptr(err_flag(self.device)), _stream()),
                    "csr_plan_build")
+
+    def _finish_build(self, what):
+        """the single host sync of a graph build: error flag + number of empty rows."""
+        raise_if_flagged(self.device, what)
+        self.n_empty = int(self._plan[:4].view(torch.int32).item())
 
     def gcn_normalize_(self):
         """val <- D^-1/2 val D^-1/2 with D = destination weight sums (PyG gcn_norm)."""
@@ -192,8 +200,8 @@ class CSRGraph:
         val = self.val if use_val else None
         ws, nbytes = self._workspace(d)
         args = (_ptr(self._plan), _ptr(self.rowptr), _ptr(self.col), _ptr(val), _ptr(x), x.stride(0), _ptr(out),
-                out.stride(0), self.n_rows, self.e_cap, d, _ptr(row_scale), _ptr(bias), ACT[act], _ptr(ws), nbytes,
-                _stream())
+                out.stride(0), self.n_rows, self.e_cap, d, _ptr(row_scale), _ptr(bias), ACT[act], self.n_empty,
+                _ptr(ws), nbytes, _stream())
         if x.dtype == torch.float32:
             _lib.check(lib.lpg_csr_spmm_f32(*args), "csr_spmm_f32")
         elif x.dtype == torch.bfloat16:

@@ -163,6 +163,7 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None):
                                       P(d_inv), nnz, P(ws), nbytes, S()), "seal_block_csr(fill)")
     g = _ops.CSRGraph(rowptr, col[:nnz] if nnz else col, val[:nnz] if nnz else val, total, total, nnz)
     g._build_plan()
+    g.n_empty = 0                       # A~ = A + I: every row holds its diagonal
     emb_dim = 0 if emb is None else emb.shape[1]
     emb = None if emb is None else _ops._c(emb, torch.float32)
     x = torch.empty((total, tags_size + emb_dim), dtype=torch.float32, device=dev)

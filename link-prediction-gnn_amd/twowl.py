@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from . import ops as _ops
-from .nn import GCNConv, GraphNorm, _forward_only
+from .nn import GCNConv, GraphNorm, _forward_only, graph_cache
 from .torch_scatter import scatter_add
 
 
@@ -82,7 +82,11 @@ class LocalWLNet(nn.Module):
 
     def forward(self, x, edge1, pos, idx=None, ei2=None, test=False):
         _forward_only(self)
-        edge2, edge2_r = reverse(ei2)                                  # K8
+        # K8: reverse(ei2) is never materialised -- the flips are folded into the two CSR builds
+        # (edge2 = (flip(e0), e1), edge2_r = (e0, flip(e1))), memoised on ei2's identity.
+        P = pos.shape[0]
+        edge2 = graph_cache.get(ei2, None, P, True, flip=1)
+        edge2_r = graph_cache.get(ei2, None, P, True, flip=2)
         x = _ops.embedding(self.emb[0].weight, x)                      # Embedding(deg)
         x = self.emb[1](x)                                             # GraphNorm (Dropout: eval identity)
         for conv1 in self.conv1s:
@@ -112,6 +116,26 @@ class LocalWLNet(nn.Module):
                 p[f"{name}.{l}.act"] = isinstance(act, nn.ReLU)
         p["pred.weight"], p["pred.bias"] = t(self.pred.weight), t(self.pred.bias)
         return p
+
+
+class CapturedForward:
+    """The scoring forward captured once into a hipGraph and replayed: ~30 kernel launches and
+    their Python/ctypes overhead collapse into one graph launch (the forward on fb-pages-food is
+    launch-bound, not bandwidth-bound).  Inputs are static: same tensors, same graph."""
+
+    def __init__(self, mod, x, ei, pos1, y_len, ei2):
+        self.args = (mod, x, ei, pos1, y_len, ei2)
+        for _ in range(2):                       # warm-up builds and caches the CSR graphs / workspaces
+            test_forward(*self.args)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = test_forward(*self.args)
+        torch.cuda.synchronize()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
 
 
 @torch.no_grad()

@@ -24,14 +24,14 @@ def test_header_symbols_exported():
 def test_workspace_queries_and_errors():
     lib = lpgnn_amd.load_library()
     assert lib.lpg_abi_version() == 1
-    assert lib.lpg_spmm_chunk_edges(1000) == 64 and lib.lpg_spmm_chunk_edges(100_000_000) == 512
+    assert lib.lpg_spmm_chunk_edges(1000) == 16 and lib.lpg_spmm_chunk_edges(100_000_000) == 512
     T = lib.lpg_spmm_chunk_edges(5_000_000)
     assert T % 64 == 0 and lib.lpg_csr_spmm_bytes(5_000_000, 128) == 2 * (-(-5_000_000 // T)) * 128 * 4 + 256
     assert lib.lpg_csr_spmm_bytes(-1, 128) < 0
     for q in (lib.lpg_csr_plan_bytes(100, 1000), lib.lpg_graphnorm_bytes(100, 32), lib.lpg_coo_to_csr_bytes(1000, 100, 1),
               lib.lpg_get_ei2_bytes(100, 1000, 100), lib.lpg_compact_cols_bytes(1000), lib.lpg_seal_block_csr_bytes(1000)):
         assert q > 0
-    rc = lib.lpg_csr_spmm_f32(0, 0, 0, 0, 0, 0, 0, 0, 5, 10, 0, 0, 0, 0, 0, 0, 0)
+    rc = lib.lpg_csr_spmm_f32(0, 0, 0, 0, 0, 0, 0, 0, 5, 10, 0, 0, 0, 0, -1, 0, 0, 0)
     assert rc == -1 and b"bad sizes" in lib.lpg_last_error()
     rc = lib.lpg_seal_subgraphs(0, 0, 10, 0, 4, 2, 100, 0, 0, 0, 0, 0, 0, 0, 0)
     assert rc == -1 and b"hop" in lib.lpg_last_error()

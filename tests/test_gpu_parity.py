@@ -198,10 +198,10 @@ def test_spmm_chunk_border_exhaustive(dev):
     import lpgnn_amd
     from oracle import aggregation as agg
     lens0 = [63, 1, 64, 65, 0, 128, 1, 1, 62, 197, 0, 0, 7]
-    T = lpgnn_amd.load_library().lpg_spmm_chunk_edges(sum(lens0))
-    assert T == 64
+    T = lpgnn_amd.load_library().lpg_spmm_chunk_edges(4 * sum(lens0))
+    assert T == 16
     rng = np.random.default_rng(3)
-    lens = [T - 1, 1, T, T + 1, 0, 2 * T, 1, 1, T - 2, 3 * T + 5, 0, 0, 7]
+    lens = [T - 1, 1, T, T + 1, 0, 2 * T, 1, 1, T - 2, 3 * T + 5, 0, 0, 7, 20 * T + 3, 1]
     n_rows, n_cols, d = len(lens), 97, 32
     dst = np.repeat(np.arange(n_rows), lens)
     src = rng.integers(0, n_cols, size=dst.size)
@@ -214,6 +214,7 @@ def test_spmm_chunk_border_exhaustive(dev):
     mag = agg.spmm_abs_rowsum(rowptr, col, None, x)
     assert np.all(np.abs(y - want) <= TOL * mag + 1e-30)
     assert np.all(y[[4, 10, 11]] == 0)
+    assert lpgnn_amd.load_library().lpg_spmm_chunk_edges(dst.size) == T
 
 
 def test_torch_sparse_signatures(dev):
@@ -493,3 +494,21 @@ def test_spmm_large_rmat_properties(dev):
         ref = x[g.col[b:e].long()].double().sum(0)
         mg = x[g.col[b:e].long()].double().abs().sum(0)
         assert torch.all((y[r].double() - ref).abs() <= TOL * mg + 1e-30)
+
+
+def test_captured_forward_matches_eager(dev, tw):
+    """hipGraph replay of the scoring forward == the eager forward, bit for bit."""
+    from lpgnn_amd import twowl
+    from oracle import twowl_int
+    torch.manual_seed(1)
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
+    ei, pred, ei2 = t(tw["test_ei"]), t(tw["test_pred"]), t(tw["test_ei2"])
+    x_deg = t(twowl_int.degree(tw["val_ei"].astype(np.int64), 620))
+    pos1 = torch.cat([ei.t(), pred.t()], 0).contiguous()
+    mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=64, channels_2wl=32).to(dev).eval()
+    eager = twowl.test_forward(mod, x_deg, ei, pos1, pred.shape[1], ei2).clone()
+    cap = twowl.CapturedForward(mod, x_deg, ei, pos1, pred.shape[1], ei2)
+    for _ in range(3):
+        out = cap()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
