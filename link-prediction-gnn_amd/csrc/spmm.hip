@@ -345,13 +345,18 @@ int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
   const int kChunk = a.chunk;
   const int64_t n_chunks = ceil_div(e_cap, kChunk);
   const Tune tn = tune();
-  // Occupancy limiter.  On big graphs the row gather runs ~9 % FASTER with ONE workgroup (4 waves,
-  // 8 x 1 KiB gathers each = 32 KiB in flight) per CU than at full occupancy (256 KiB in flight):
-  // measured 8.28 vs 9.27 ms on |E| = 100 M, d = 128 (profiles/r01/sweep_notes.md).  Reserving more
-  // than half of the CU's 160 KiB LDS per workgroup admits exactly one.  Small graphs are latency
-  // bound and keep the default.
+  // Occupancy limiter.  On big graphs the row gather runs FASTER with one or two workgroups per CU
+  // than at full occupancy (profiles/r01/sweep_notes.md): fp32 d=128  9.27 ms full -> 8.94 (2/CU) ->
+  // 8.28 (1/CU); fp32 d=64  4.65 -> 4.20 (2/CU) | 4.61 (1/CU); bf16 d=128  5.18 -> 4.76 (2/CU) |
+  // 6.17 (1/CU: the bf16 widen leaves too little overlap with one wave per SIMD).  Reserving LDS
+  // per workgroup admits exactly that many: > 80 KiB -> one, 64 KiB -> two of the CU's 160 KiB.
+  // Small graphs are latency bound and keep the default.
   int lds = tn.lds;
-  if (lds < 0) lds = (e_cap >= (int64_t(1) << 20) && G * VEC * sizeof(T) >= 256) ? 90000 : 0;
+  if (lds < 0) {
+    lds = 0;
+    if (e_cap >= (int64_t(1) << 20))
+      lds = (sizeof(T) == 4 && G * VEC * sizeof(T) >= 512) ? 90000 : 65536;
+  }
   const int64_t n_waves = ceil_div(n_chunks, GPW);
   const int64_t n_blocks = ceil_div(n_waves, tn.block / kWave);
   const dim3 blk(tn.block);

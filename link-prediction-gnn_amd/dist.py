@@ -61,12 +61,15 @@ class SourcePartitionedSpMM:
                 w = None if edge_weight is None else edge_weight[m]
                 self.graphs.append(CSRGraph.from_edge_index(ei, r1 - r0, hi - lo, edge_weight=w))
 
+    def nnz(self):
+        return sum(g.nnz() for g in self.graphs)
+
     def forward(self, x_local, out=None):
         import torch.distributed as dist
         d = x_local.shape[1]
         y = out if out is not None else torch.empty((self.n_nodes, d), dtype=x_local.dtype, device=x_local.device)
         works = []
-        use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        use_dist = dist.is_available() and dist.is_initialized()
         for k, (r0, r1) in enumerate(self.blocks):
             blk = y[r0:r1]
             if self.block_spmm is not None:

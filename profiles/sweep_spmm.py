@@ -17,10 +17,11 @@ import bench  # noqa: E402
 KEYS = ["LPG_SPMM_CHUNK", "LPG_SPMM_U", "LPG_SPMM_MODE", "LPG_SPMM_LDS", "LPG_SPMM_PIPE", "LPG_SPMM_BLOCK"]
 variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[1:]] or [{}]
 dev = torch.device("cuda:0")
-N, E, d = 5_000_000, 100_000_000, 128
-g, x = bench.make_rmat_problem(N, E, d, seed=5, device=dev)
+N, E, d = 5_000_000, 100_000_000, int(os.environ.get("SWEEP_D", "128"))
+DT = torch.bfloat16 if os.environ.get("SWEEP_DTYPE") == "bf16" else torch.float32
+g, x = bench.make_rmat_problem(N, E, d, seed=5, device=dev, dtype=DT)
 nnz = g.nnz()
-alg = bench.spmm_algorithmic_bytes(N, nnz, d)
+alg = bench.spmm_algorithmic_bytes(N, nnz, d, 2 if DT == torch.bfloat16 else 4)
 times = {i: [] for i in range(len(variants))}
 ROUNDS, STEPS = 4, 8
 for rnd in range(ROUNDS):
@@ -41,5 +42,5 @@ for rnd in range(ROUNDS):
 for i, v in enumerate(variants):
     t = times[i]
     med = statistics.median(t)
-    print(json.dumps({"variant": v, "ms_median": round(med, 3), "ms_min": round(min(t), 3), "ms_max": round(max(t), 3),
+    print(json.dumps({"d": d, "dtype": str(DT)[6:], "variant": v, "ms_median": round(med, 3), "ms_min": round(min(t), 3), "ms_max": round(max(t), 3),
                       "frac_of_8TBs": round(alg / (med * 1e-3) / 8e12, 4)}), flush=True)
