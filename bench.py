@@ -11,9 +11,11 @@ kernels of lpg_csr_spmm_f32) with graph, plan and X already resident in HBM.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the north star's
 source-edge partition -- rank g owns source rows [g*V/N, (g+1)*V/N) of X and the |E| = 100 M
-edges that leave them (weak scaling: per-GPU edges fixed), computes a partial Y_g[V, d] and the
-partials are summed with an RCCL all-reduce, row-block pipelined against the SpMM of the next
-block.  value = edges aggregated by ALL ranks per second (max-over-ranks time).
+edges that leave them (weak scaling: per-GPU edges fixed), computes a partial Y_g[V, d], and the
+partials are summed over xGMI with an RCCL reduce-scatter (default: every rank keeps the rows of
+its own range, which is what the next layer on the same partition reads; --collective all_reduce
+gives the full Y everywhere), pipelined in stages against the SpMM of the next stage.
+value = edges aggregated by ALL ranks per second (max-over-ranks time).
 
 Prints ONE JSON line (rank 0).  Extra objects: roofline (HBM, dominant kernel), cpu_baseline
 (the torch_scatter CPU path restated, bounded sample, N = 1 only), twowl (the reference's own
@@ -220,7 +222,9 @@ def main():
     ap.add_argument("--edges", type=int, default=100_000_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
-    ap.add_argument("--blocks", type=int, default=8, help="row blocks for compute/all-reduce overlap (N > 1)")
+    ap.add_argument("--blocks", type=int, default=4, help="pipeline stages for compute/collective overlap (N > 1)")
+    ap.add_argument("--collective", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
+                    help="how the per-rank partial aggregates are summed (N > 1); see lpgnn_amd/dist.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-twowl", action="store_true")
     args = ap.parse_args()
@@ -258,7 +262,7 @@ def main():
         gen = torch.Generator(device=device)
         gen.manual_seed(1005 + rank)
         x = torch.randn((hi - lo, d), generator=gen, device=device).to(dtype)
-        runner = ldist.SourcePartitionedSpMM(ei, N, (lo, hi), n_blocks=args.blocks)
+        runner = ldist.SourcePartitionedSpMM(ei, N, (lo, hi), n_blocks=args.blocks, collective=args.collective)
         del ei
         g = None
     torch.cuda.synchronize()
@@ -303,8 +307,8 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"RMAT(0.57,0.19,0.19,0.05) CSR-SpMM |V|={N} |E|={E}/GPU d={d} {args.dtype}, unweighted, "
                                "int32 col / int64 rowptr; north_star 1-GPU target instance (SURVEY 8d config 5 generator, seed 5)",
-                   "parallelism": "single GPU" if world == 1 else f"source-edge partition x{world} + RCCL all-reduce of Y[V,d] "
-                                                                    f"({args.blocks} row blocks, overlapped)",
+                   "parallelism": "single GPU" if world == 1 else f"source-edge partition x{world} + RCCL {args.collective} of the "
+                                                                    f"partial Y[V,d] ({args.blocks} stages, overlapped with the SpMM)",
                    "graph_build_s": t_build},
     }
     if rank == 0:

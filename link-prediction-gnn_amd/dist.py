@@ -1,13 +1,21 @@
-"""Multi-GPU aggregation: the north star's source-edge partition with an RCCL all-reduce.
+"""Multi-GPU aggregation: the north star's source-edge partition with an RCCL reduction.
 
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).  Rank g owns the
 source-node range [g*V/G, (g+1)*V/G): the rows of X in that range and every edge that leaves
-them.  It computes a partial Y_g[V, d] over its edges; Y = sum_g Y_g is an all-reduce.
+them.  It computes a partial Y_g[V, d] over its edges; Y = sum_g Y_g.
 
-xGMI is point-to-point and the all-reduce moves ~2x the [V, d] partial per rank, which is more
-time than the local SpMM.  So the destination rows are cut into row
-blocks and the all-reduce of block k is issued asynchronously while the SpMM of block k+1 runs:
-the collective of every block but the last hides behind compute (or vice versa).
+Which collective.  all-reduce = reduce-scatter + all-gather.  The consumer of Y in a source-
+partitioned multi-layer GNN is the next layer on the SAME partition, which reads only the rows of
+its own range -- exactly the shard a reduce-scatter leaves on each rank.  So the default is
+``collective="reduce_scatter"`` (rank g ends up with Y[lo_g:hi_g], fully reduced; (G-1)/G * V*d*4
+bytes per rank instead of twice that); ``collective="all_reduce"`` is the literal north-star form
+and returns the full Y on every rank.
+
+Overlap.  xGMI is point-to-point, and even the reduce-scatter of a [V, d] fp32 partial moves more
+bytes than the local SpMM takes time for on few GPUs.  The destination rows
+are therefore cut into S stages; stage s holds sub-block s of EVERY rank's shard, laid out
+[G, rows, d] so that one reduce_scatter_tensor serves it, and the collective of stage s is issued
+asynchronously while the SpMM of stage s+1 runs.
 
 The reference has no distributed code at all; this file has no reference counterpart.
 """
@@ -17,7 +25,7 @@ import torch
 
 
 def source_range(n_nodes: int, world: int, rank: int) -> Tuple[int, int]:
-    """contiguous, balanced source-node ranges; the last ranks get the remainder."""
+    """contiguous, balanced source-node ranges; the first ranks get the remainder."""
     base, rem = divmod(n_nodes, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
@@ -35,49 +43,124 @@ def partition_edges_by_source(edge_index: torch.Tensor, n_nodes: int, world: int
     return edge_index[:, m]
 
 
+def shard_layout(n_nodes: int, world: int, n_stages: int) -> Tuple[int, int]:
+    """(rows per rank shard, rows per stage sub-block): equal, padded shards so that one
+    reduce_scatter_tensor per stage works.  Shard r covers destination rows
+    [r*shard, (r+1)*shard) of the padded row space; rows >= n_nodes are padding (no edges)."""
+    shard = -(-n_nodes // world)
+    n_stages = max(1, min(n_stages, shard)) if shard > 0 else 1
+    sub = -(-shard // n_stages)
+    return sub * n_stages, sub
+
+
 class SourcePartitionedSpMM:
     """Y = A @ X with A's edges partitioned by source across ranks.
 
     edge_index_local: [2, E_local] int64 with GLOBAL ids; every source must lie in `src_range`.
-    forward(x_local [hi-lo, d]) returns the full, all-reduced Y [V, d] on every rank.
-    `block_spmm` (tests): callable (k, row0, row1, x_local) -> partial block, replacing the HIP path.
+    forward(x_local [hi-lo, d]):
+        collective="reduce_scatter" -> this rank's shard  Y[rank*shard : (rank+1)*shard]  (padded)
+        collective="all_reduce"     -> the full Y [V, d] on every rank
+    `block_spmm` (CPU tests): callable (stage, dst_rows LongTensor, x_local) -> partial rows for
+    those destination rows, replacing the HIP path.
     """
 
-    def __init__(self, edge_index_local, n_nodes, src_range, n_blocks=8, edge_weight=None, group=None,
-                 block_spmm: Optional[Callable] = None):
+    def __init__(self, edge_index_local, n_nodes, src_range, n_blocks=4, edge_weight=None, group=None,
+                 block_spmm: Optional[Callable] = None, collective="reduce_scatter", world=None, rank=None):
+        import torch.distributed as dist
         self.n_nodes, self.src_range, self.group = int(n_nodes), src_range, group
-        lo, hi = src_range
-        self.blocks = row_blocks(self.n_nodes, n_blocks)
+        self.collective = collective
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = world if world is not None else (dist.get_world_size(group) if ready else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if ready else 0)
+        self.shard, self.sub = shard_layout(self.n_nodes, self.world, n_blocks)
+        self.n_stages = self.shard // self.sub
         self.block_spmm = block_spmm
         self.graphs = []
+        lo, hi = src_range
+        dev = edge_index_local.device
+        # stage s covers, for every rank r, padded rows [r*shard + s*sub, r*shard + (s+1)*sub)
+        self.stage_rows = []
+        for s in range(self.n_stages):
+            base = torch.arange(self.world, device=dev).view(-1, 1) * self.shard + s * self.sub
+            self.stage_rows.append((base + torch.arange(self.sub, device=dev).view(1, -1)).reshape(-1))
         if block_spmm is None:
             from .ops import CSRGraph
             src, dst = edge_index_local[0] - lo, edge_index_local[1]
             if edge_index_local.numel() and (int(src.min()) < 0 or int(src.max()) >= hi - lo):
                 raise ValueError("SourcePartitionedSpMM: an edge's source is outside this rank's range")
-            for (r0, r1) in self.blocks:
-                m = (dst >= r0) & (dst < r1)
-                ei = torch.stack([src[m], dst[m] - r0])
+            owner = torch.div(dst, self.shard, rounding_mode="floor")
+            within = dst - owner * self.shard
+            stage = torch.div(within, self.sub, rounding_mode="floor")
+            local = owner * self.sub + (within - stage * self.sub)          # row inside the stage buffer
+            for s in range(self.n_stages):
+                m = stage == s
+                ei = torch.stack([src[m], local[m]])
                 w = None if edge_weight is None else edge_weight[m]
-                self.graphs.append(CSRGraph.from_edge_index(ei, r1 - r0, hi - lo, edge_weight=w))
+                self.graphs.append(CSRGraph.from_edge_index(ei, self.world * self.sub, hi - lo, edge_weight=w))
+        self._stage_buf = {}
 
     def nnz(self):
         return sum(g.nnz() for g in self.graphs)
 
+    def _buffers(self, d, dtype, device):
+        key = (d, dtype)
+        if key not in self._stage_buf:
+            self._stage_buf[key] = [torch.empty((self.world * self.sub, d), dtype=dtype, device=device)
+                                    for _ in range(min(self.n_stages, 3))]      # ring of staging buffers
+        return self._stage_buf[key]
+
     def forward(self, x_local, out=None):
         import torch.distributed as dist
         d = x_local.shape[1]
-        y = out if out is not None else torch.empty((self.n_nodes, d), dtype=x_local.dtype, device=x_local.device)
-        works = []
+        dev, dt = x_local.device, x_local.dtype
         use_dist = dist.is_available() and dist.is_initialized()
-        for k, (r0, r1) in enumerate(self.blocks):
-            blk = y[r0:r1]
+        backend = dist.get_backend(self.group) if use_dist else None
+        asyn = use_dist and backend != "gloo"
+        bufs = self._buffers(d, dt, dev)
+        rs = self.collective == "reduce_scatter"
+        if rs:
+            y = out if out is not None else torch.empty((self.shard, d), dtype=dt, device=dev)
+        else:       # padded row space [world, n_stages, sub, d]; the caller gets the first n_nodes rows
+            full = torch.empty((self.world * self.shard, d), dtype=dt, device=dev)
+            full4 = full.view(self.world, self.n_stages, self.sub, d)
+        pending = [None] * len(bufs)          # (work, stage) whose staging buffer is still in use
+
+        def retire(slot):
+            if pending[slot] is None:
+                return
+            work, st = pending[slot]
+            if work is not None:
+                work.wait()
+            if not rs:                        # all-reduced stage rows go back to their global positions
+                full4[:, st].copy_(bufs[slot].view(self.world, self.sub, d))
+            pending[slot] = None
+
+        for s in range(self.n_stages):
+            slot = s % len(bufs)
+            retire(slot)
+            buf = bufs[slot]
             if self.block_spmm is not None:
-                blk.copy_(self.block_spmm(k, r0, r1, x_local))
+                buf.copy_(self.block_spmm(s, self.stage_rows[s], x_local))
             else:
-                self.graphs[k].spmm(x_local, out=blk)
-            if use_dist:       # async: the collective of block k overlaps the SpMM of block k+1
-                works.append(dist.all_reduce(blk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
-            w.wait()
-        return y
+                self.graphs[s].spmm(x_local, out=buf)
+            work = None
+            if rs:
+                dst = y[s * self.sub:(s + 1) * self.sub]
+                if asyn:                      # overlaps the SpMM of stage s+1
+                    work = dist.reduce_scatter_tensor(dst, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                else:                         # no process group, or gloo (no reduce_scatter): CPU test path
+                    if use_dist:
+                        dist.all_reduce(buf, group=self.group)
+                    dst.copy_(buf[self.rank * self.sub:(self.rank + 1) * self.sub])
+            elif use_dist:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=asyn)
+                work = work if asyn else None
+            pending[slot] = (work, s)
+        for slot in range(len(bufs)):
+            retire(slot)
+        if rs:
+            return y
+        if out is not None:
+            out.copy_(full[: self.n_nodes])
+            return out
+        return full[: self.n_nodes]

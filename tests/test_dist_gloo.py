@@ -36,16 +36,31 @@ def _worker(rank, world, port, q):
     mine = ldist.partition_edges_by_source(torch.from_numpy(ei), n, world, rank).numpy()
     assert mine.shape[1] > 0 and mine[0].min() >= lo and mine[0].max() < hi
 
-    def block_spmm(k, r0, r1, x_local):
-        m = (mine[1] >= r0) & (mine[1] < r1)
-        rowptr, col, _, _ = agg.coo_to_csr(mine[1][m] - r0, mine[0][m] - lo, r1 - r0)
+    def block_spmm(stage, rows, x_local):
+        """partial aggregate of this rank's edges for the given (padded) destination rows."""
+        rows = rows.numpy()
+        pos = np.full(rows.max() + 2, -1, dtype=np.int64)
+        pos[rows] = np.arange(rows.size)
+        keep = pos[np.minimum(mine[1], rows.max() + 1)] >= 0
+        keep &= mine[1] <= rows.max()
+        rowptr, col, _, _ = agg.coo_to_csr(pos[mine[1][keep]], mine[0][keep] - lo, rows.size)
         return torch.from_numpy(agg.csr_spmm(rowptr, col, None, x_local.numpy()))
 
-    op = ldist.SourcePartitionedSpMM(torch.from_numpy(mine), n, (lo, hi), n_blocks=5, block_spmm=block_spmm)
-    y = op.forward(torch.from_numpy(x[lo:hi]))
     rowptr, col, _, _ = agg.coo_to_csr(ei[1], ei[0], n)
     want = agg.csr_spmm(rowptr, col, None, x)
-    q.put((rank, float(np.abs(y.numpy() - want).max()), mine.shape[1]))
+    errs = []
+    for collective in ("reduce_scatter", "all_reduce"):
+        op = ldist.SourcePartitionedSpMM(torch.from_numpy(mine), n, (lo, hi), n_blocks=5, block_spmm=block_spmm,
+                                         collective=collective)
+        y = op.forward(torch.from_numpy(x[lo:hi])).numpy()
+        if collective == "reduce_scatter":       # this rank's (padded) shard of the destination rows
+            r0 = rank * op.shard
+            ref = np.zeros((op.shard, d))
+            ref[: max(0, min(n, r0 + op.shard) - r0)] = want[r0:r0 + op.shard]
+            errs.append(float(np.abs(y - ref).max()))
+        else:
+            errs.append(float(np.abs(y - want).max()))
+    q.put((rank, max(errs), mine.shape[1]))
     dist.destroy_process_group()
 
 
@@ -73,3 +88,5 @@ def test_ranges_cover_and_balance():
         sizes = [b - a for a, b in r]
         assert max(sizes) - min(sizes) <= 1
     assert ldist.row_blocks(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert ldist.shard_layout(5_000_000, 8, 4) == (625_000, 156_250)
+    assert ldist.shard_layout(203, 2, 5) == (105, 21)

@@ -512,3 +512,26 @@ def test_captured_forward_matches_eager(dev, tw):
         out = cap()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_source_partitioned_spmm_layout_on_gpu(dev):
+    """the N > 1 staging layout on the HIP kernels, two 'ranks' emulated in one process: summing
+    the per-rank partial shards reproduces the single-GPU SpMM (the collective itself is covered
+    by the gloo world-2 test on CPU)."""
+    import lpgnn_amd
+    from lpgnn_amd import dist as ldist
+    rng = np.random.default_rng(8)
+    n, e, d, world = 1003, 40000, 32, 2
+    ei = torch.from_numpy(rand_graph(rng, n, n, e, hub=0.1)).to(dev)
+    x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(dev)
+    want = lpgnn_amd.CSRGraph.from_edge_index(ei, n, n).spmm(x)
+    shard, _ = ldist.shard_layout(n, world, 3)
+    got = torch.zeros((world * shard, d), device=dev)
+    for q in range(world):                       # shard owner
+        for r in range(world):                   # contributing rank
+            lo, hi = ldist.source_range(n, world, r)
+            mine = ldist.partition_edges_by_source(ei, n, world, r)
+            op = ldist.SourcePartitionedSpMM(mine, n, (lo, hi), n_blocks=3, world=world, rank=q)
+            got[q * shard:(q + 1) * shard] += op.forward(x[lo:hi])
+    assert torch.allclose(got[:n], want, rtol=1e-5, atol=1e-5)
+    assert torch.all(got[n:] == 0)
