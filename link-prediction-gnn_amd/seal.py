@@ -99,6 +99,53 @@ def _host_capped_nodes(pair, rowptr, col, max_neighbors, rng):
     return [u, v] + sorted(sub)
 
 
+def _rank_auc(y, s):
+    """ROC AUC with average ranks for ties (== sklearn.metrics.roc_auc_score)."""
+    s = s.double()
+    order = torch.argsort(s, stable=True)
+    ss = s[order]
+    first = torch.ones_like(ss, dtype=torch.bool)
+    first[1:] = ss[1:] != ss[:-1]
+    grp = torch.cumsum(first, 0) - 1
+    cnt = torch.bincount(grp)
+    start = torch.cumsum(cnt, 0) - cnt
+    avg = (start.double() + (cnt.double() - 1) / 2 + 1)[grp]
+    ranks = torch.empty_like(avg)
+    ranks[order] = avg
+    y = y.bool()
+    npos, nneg = int(y.sum()), int((~y).sum())
+    return float((ranks[y].sum() - npos * (npos + 1) / 2) / (npos * nneg))
+
+
+def auto_hop(positive, negative, graph, test_ratio=0.1):
+    """SEAL/config/subgraph.py:44-63 -- hop = 1 if AUC(common neighbours) > AUC('aa') else 2 on the
+    held-out pairs.  Restated as the reference computes it: cn = A @ A in **uint8** (wraps mod 256),
+    aa = A @ (A / log(rowsum A)) with nan/inf -> 0, i.e. aa[u,v] = cn[u,v] / log(deg v) (the
+    reference divides COLUMN j by log(deg j))."""
+    dev = graph.rowptr.device
+    positive, negative = np.asarray(positive), np.asarray(negative)
+    test_size = int(len(positive) * test_ratio)
+    pairs = torch.as_tensor(np.concatenate([positive[-test_size:], negative[-test_size:]]), dtype=torch.int64, device=dev)
+    y = torch.cat([torch.ones(test_size, device=dev), torch.zeros(test_size, device=dev)])
+    n = graph.n_nodes
+    deg = (graph.rowptr[1:] - graph.rowptr[:-1])
+    keys = torch.repeat_interleave(torch.arange(n, device=dev), deg) * n + graph.col.long()    # sorted (row, col) keys
+    u, v = pairs[:, 0], pairs[:, 1]
+    du = deg[u]
+    pid = torch.repeat_interleave(torch.arange(pairs.shape[0], device=dev), du)
+    off = torch.arange(int(du.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(du, 0) - du, du)
+    w = graph.col.long()[graph.rowptr[u][pid] + off]                  # every neighbour w of u, per pair
+    probe = w * n + v[pid]
+    pos = torch.searchsorted(keys, probe).clamp(max=keys.numel() - 1)
+    hit = keys[pos] == probe                                          # A[w, v] == 1
+    cn = torch.zeros(pairs.shape[0], dtype=torch.int64, device=dev).index_add_(0, pid, hit.long())
+    cn_u8 = (cn % 256).double()                                       # np.matmul on uint8 wraps
+    logd = torch.log(deg[v].double())
+    aa = cn.double() / logd                                           # float64 path: no wrap
+    aa[torch.isnan(aa) | torch.isinf(aa)] = 0.0
+    return 1 if _rank_auc(y, cn_u8) > _rank_auc(y, aa) else 2
+
+
 def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=0, max_neighbors=100, seed=0,
                   device="cuda"):
     """SEAL/config/subgraph.py:11-102 for hop in {0, 1}: negatives first, then positives (:74).
@@ -106,10 +153,12 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
     the global compaction (:84-101) applied when features are built."""
     if network_type != 0:
         raise NotImplementedError("the reference is run undirected (network_type=0)")
-    if hop == "auto":
-        raise NotImplementedError("hop='auto' (CN/AA AUC heuristic, :44-63) is host-side model selection; "
-                                  "fb-pages-food selects hop=1 (tests/golden/seal_int.npz: auto_hop_line)")
     graph = build_train_csr(positive, nodes_size, test_ratio, device)
+    if hop == "auto":
+        hop = auto_hop(positive, negative, graph, test_ratio)
+        if hop != 1:
+            raise NotImplementedError("the heuristic selected hop=2, which the reference itself cannot run "
+                                      "(SEAL/config/subgraph.py:122,131 shuffles a set)")
     pairs = np.concatenate([np.asarray(negative), np.asarray(positive)]).astype(np.int64)
     batch = extract_subgraphs(pairs, graph, hop, max_neighbors)
     capped = batch.capped.bool()
