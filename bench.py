@@ -173,13 +173,16 @@ def twowl_forward_bench(device, iters=50):
 def seal_forward_bench(device, iters=10):
     """configs[0] on the GPU: SEAL's structure + aggregation forward over ALL 4202 fb-pages-food
     candidate pairs as one batch (hop 1): enclosing subgraphs + DRNL (a10/a11), block-diagonal
-    A~ / D^-1 / X (a12), four graph-conv layers with the shipped checkpoint's weights (a9).
+    A~ / D^-1 / X (a12), four graph-conv layers (a9) and the SortPooling/conv1d/dense head, all with
+    the shipped checkpoint's weights.
     The reference runs one sess.run per subgraph (~2.15 K subgraph passes/s recorded)."""
     import numpy as np
     from lpgnn_amd import seal
     z = np.load(os.path.join(ROOT, "tests", "golden", "seal_int.npz"))
     wz = np.load(os.path.join(ROOT, "tests", "golden", "seal_weights.npz"))
     weights = [torch.from_numpy(wz[f"graph_weight_{i}"]).to(device) for i in (1, 2, 3, 4)]
+    hw = {k: torch.from_numpy(wz[k]).to(device) for k in ("conv1d_kernel_1", "conv1d_kernel_2", "weight_1", "bias_1",
+                                                          "weight_2", "bias_2")}
     pos, neg = z["positive"].astype(np.int64), z["negative"].astype(np.int64)
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
@@ -190,7 +193,8 @@ def seal_forward_bench(device, iters=10):
 
     def aggregate(batch, tag_map, T):
         g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb)
-        return seal.graph_conv_stack(g, d_inv, x, weights)
+        zc, key = seal.graph_conv_stack(g, d_inv, x, weights)
+        return seal.head(zc, key, batch.node_off(), hw)[1]       # P(link) per candidate
 
     batch, _, T, tag_map, _ = structure()
     aggregate(batch, tag_map, T)
@@ -206,7 +210,8 @@ def seal_forward_bench(device, iters=10):
     torch.cuda.synchronize()
     t_agg = (time.time() - t0) / iters
     B = batch.B
-    return {"workload": "fb-pages-food SEAL hop-1, all 4202 candidate pairs in one batch, checkpoint graph-conv weights",
+    return {"workload": "fb-pages-food SEAL hop-1 scoring forward (subgraphs + DRNL + 4 graph convs + DGCNN head), all 4202 "
+                        "candidate pairs in one batch, shipped checkpoint weights",
             "scored_edges": B, "total_vertices": int(batch.n.sum().item()),
             "structure_ms": t_struct * 1e3, "aggregation_ms": t_agg * 1e3,
             "scored_edges_per_s": B / (t_struct + t_agg),

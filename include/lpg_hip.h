@@ -117,9 +117,10 @@ int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* co
 /* ---------------------------------------------------------------- dense feature linear (K5)
  * Y[n,m] = X[n,k] @ W^T (+ bias), W is [m,k] (nn.Linear / GCNConv.lin layout) or, with
  * w_is_km != 0, [k,m] (SEAL's tf.matmul(X, W), SEAL/model/gnn.py:46,50,54,58).
- * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products). */
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products).
+ * act: LPG_ACT_* applied after the bias (SEAL's dense layer relu(x W + b), SEAL/model/gnn.py:127). */
 int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias,
-                   float* y, int64_t ldy, int64_t n, int64_t k, int64_t m, void* stream);
+                   int act, float* y, int64_t ldy, int64_t n, int64_t k, int64_t m, void* stream);
 
 /* ---------------------------------------------------------------- GraphNorm (K6)
  * torch_geometric.nn.GraphNorm.forward(x, batch=None) [TwoWL/model/model.py:38,54]:
@@ -197,6 +198,16 @@ int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_nodes, const in
                           const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len,
                           int64_t T, const float* emb, int64_t emb_dim, int64_t B, float* x,
                           int64_t ldx, int32_t* err_flag, void* stream);
+
+/* ---------------------------------------------------------------- SEAL head
+ * SortPooling [SEAL/model/gnn.py:82-91]: per subgraph b, order its n_b vertices by key (= Z_4[:,0])
+ * descending, ties -> lower vertex index first (tf.nn.top_k), take the first k rows of z
+ * (= concat(Z1,Z2,Z3), C columns) and zero-pad to k rows:  out[b, t, :], out is [B, k, C].
+ * The 1-D convolutions and dense layers that follow (:103-137) are plain matmuls on this layout
+ * and run on lpg_linear_f32.  pos_score: softmax(pre_y)[:, 1] for the 2-class logits (:137). */
+int lpg_seal_sortpool_f32(const float* z, int64_t ldz, const float* key, const int64_t* node_off,
+                          int64_t B, int64_t k, int64_t C, float* out, void* stream);
+int lpg_softmax2_pos_score_f32(const float* pre_y, int64_t B, float* score, void* stream);
 
 #ifdef __cplusplus
 }

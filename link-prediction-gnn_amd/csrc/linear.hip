@@ -18,7 +18,7 @@ constexpr int LDP = KT + 1;  // padded LDS row
 
 __global__ __launch_bounds__(kBlock) void linear_mfma_f32_kernel(const float* __restrict__ x, int64_t ldx,
                                                                  const float* __restrict__ w, int w_is_km,
-                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ bias, int act,
                                                                  float* __restrict__ y, int64_t ldy, int64_t n,
                                                                  int64_t k, int64_t m) {
   __shared__ float Xs[4][32][LDP];
@@ -66,21 +66,22 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_f32_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < n) y[row * ldy + col] = acc[r] + b;
+      if (row < n) y[row * ldy + col] = apply_act(acc[r] + b, act);
     }
   }
 }
 }  // namespace
 
-LPG_EXPORT int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, float* y,
-                              int64_t ldy, int64_t n, int64_t k, int64_t m, void* stream) {
-  LPG_REQUIRE(n >= 0 && k >= 1 && m >= 1 && ldx >= k && ldy >= m, "linear: bad sizes n=%lld k=%lld m=%lld",
+LPG_EXPORT int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, int act,
+                              float* y, int64_t ldy, int64_t n, int64_t k, int64_t m, void* stream) {
+  LPG_REQUIRE(act >= LPG_ACT_NONE && act <= LPG_ACT_TANH, "linear: unknown activation");
+  LPG_REQUIRE(n >= 0 && k >= 1 && m >= 1 && ldx >= 1 && ldy >= m, "linear: bad sizes n=%lld k=%lld m=%lld",
               (long long)n, (long long)k, (long long)m);
   if (n == 0) return LPG_OK;
   LPG_REQUIRE(x && w && y, "linear: null pointer");
   const int64_t gx = ceil_div(n, 128), gy = ceil_div(m, 32);
   LPG_REQUIRE(gx < (int64_t(1) << 31) && gy < 65536, "linear: grid too large");
   hipLaunchKernelGGL(linear_mfma_f32_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), dim3(kBlock),
-                     0, as_stream(stream), x, ldx, w, w_is_km, bias, y, ldy, n, k, m);
+                     0, as_stream(stream), x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m);
   return check_launch("linear");
 }

@@ -299,6 +299,49 @@ __global__ __launch_bounds__(kBlock) void seal_features_kernel(const int32_t* __
     x[g * ldx + c] = v;
   }
 }
+// ---- SortPooling: one workgroup per subgraph; rank sort of <= 128 keys in LDS -------------------
+__global__ __launch_bounds__(kSealBlock) void seal_sortpool_kernel(const float* __restrict__ z, int64_t ldz,
+                                                                   const float* __restrict__ key,
+                                                                   const int64_t* __restrict__ node_off, int64_t B,
+                                                                   int64_t k, int64_t C, float* __restrict__ out) {
+  __shared__ float keys[MAXN];
+  __shared__ int order[MAXN];     // order[rank] = vertex
+  const int t = threadIdx.x;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    const int64_t base = node_off[b];
+    int n = static_cast<int>(node_off[b + 1] - base);
+    if (n > MAXN) n = MAXN;
+    if (t < n) keys[t] = key[base + t];
+    __syncthreads();
+    if (t < n) {
+      const float mine = keys[t];
+      int rank = 0;                // number of vertices that come before t: larger key, or equal key and lower index
+      for (int j = 0; j < n; ++j) {
+        const float o = keys[j];
+        rank += (o > mine) || (o == mine && j < t);
+      }
+      order[rank] = t;
+    }
+    __syncthreads();
+    const int64_t total = k * C;
+    for (int64_t q = t; q < total; q += kSealBlock) {
+      const int64_t r = q / C, c = q - r * C;
+      out[(b * k + r) * C + c] = r < n ? z[(base + order[r]) * ldz + c] : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void softmax2_kernel(const float* __restrict__ pre_y, int64_t B,
+                                                          float* __restrict__ score) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; b < B; b += stride) {
+    const float y0 = pre_y[2 * b], y1 = pre_y[2 * b + 1];
+    const float m = fmaxf(y0, y1);
+    const float e0 = expf(y0 - m), e1 = expf(y1 - m);
+    score[b] = e1 / (e0 + e1);
+  }
+}
 }  // namespace
 
 LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
@@ -371,4 +414,23 @@ LPG_EXPORT int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_node
     hipLaunchKernelGGL(seal_features_kernel, dim3(grid_for(total * (T + emb_dim))), dim3(kBlock), 0, st, nodes, node_off, tags,
                        tag_map, tag_map_len, T, emb, emb_dim, B, total, x, ldx, err_flag);
   return check_launch("seal_features");
+}
+
+LPG_EXPORT int lpg_seal_sortpool_f32(const float* z, int64_t ldz, const float* key, const int64_t* node_off, int64_t B,
+                                     int64_t k, int64_t C, float* out, void* stream) {
+  LPG_REQUIRE(B >= 0 && k >= 1 && C >= 1 && ldz >= C, "seal_sortpool: bad sizes");
+  if (B == 0) return LPG_OK;
+  LPG_REQUIRE(z && key && node_off && out, "seal_sortpool: null pointer");
+  const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
+  hipLaunchKernelGGL(seal_sortpool_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), z, ldz, key, node_off, B,
+                     k, C, out);
+  return check_launch("seal_sortpool");
+}
+
+LPG_EXPORT int lpg_softmax2_pos_score_f32(const float* pre_y, int64_t B, float* score, void* stream) {
+  LPG_REQUIRE(B >= 0, "softmax2: bad size");
+  if (B == 0) return LPG_OK;
+  LPG_REQUIRE(pre_y && score, "softmax2: null pointer");
+  hipLaunchKernelGGL(softmax2_kernel, dim3(grid_for(B)), dim3(kBlock), 0, as_stream(stream), pre_y, B, score);
+  return check_launch("softmax2");
 }

@@ -212,20 +212,26 @@ class CSRGraph:
 
 
 # ------------------------------------------------------------------------------ dense / norm
-def linear(x, weight, bias=None, w_is_km=False, out=None):
-    """x [n,k] @ weight^T (+bias); weight [m,k] (nn.Linear) or [k,m] when w_is_km."""
+def linear(x, weight, bias=None, w_is_km=False, out=None, act=None, n=None, ldx=None):
+    """x [n,k] @ weight^T (+bias, act); weight [m,k] (nn.Linear) or [k,m] when w_is_km.
+    n / ldx: treat x's storage as n rows of k values every ldx elements (overlapping windows, e.g.
+    SEAL's width-5 conv1d as a matmul over a [B*k,16] buffer with ldx=16, k=80)."""
     lib = _lib.load()
     _need_gpu(x, weight, bias)
     x = _c(x, torch.float32)
     weight = _c(weight, torch.float32)
     bias = _c(bias, torch.float32)
-    n, k = x.shape
+    k = weight.shape[0] if w_is_km else weight.shape[1]
     m = weight.shape[1] if w_is_km else weight.shape[0]
-    if (weight.shape[0] if w_is_km else weight.shape[1]) != k:
-        raise ValueError(f"linear: shape mismatch x {tuple(x.shape)} w {tuple(weight.shape)}")
+    if n is None:
+        if x.dim() != 2 or x.shape[1] != k:
+            raise ValueError(f"linear: shape mismatch x {tuple(x.shape)} w {tuple(weight.shape)}")
+        n, ldx = x.shape[0], x.stride(0)
+    elif (n - 1) * ldx + k > x.numel():
+        raise ValueError("linear: (n, ldx, k) window runs past the end of x")
     if out is None:
         out = torch.empty((n, m), dtype=torch.float32, device=x.device)
-    _lib.check(lib.lpg_linear_f32(_ptr(x), x.stride(0), _ptr(weight), int(w_is_km), _ptr(bias), _ptr(out),
+    _lib.check(lib.lpg_linear_f32(_ptr(x), ldx, _ptr(weight), int(w_is_km), _ptr(bias), ACT[act], _ptr(out),
                                   out.stride(0), n, k, m, _stream()), "linear_f32")
     return out
 

@@ -232,3 +232,49 @@ def graph_conv_stack(g, d_inv, x, weights):
         z = g.spmm(h, row_scale=d_inv, act="tanh")                # K10: one fused kernel per layer
         zs.append(z)
     return torch.cat(zs[:3], dim=1), zs[3][:, 0]
+
+
+def sortpool(z, key, node_off, k):
+    """SortPooling (SEAL/model/gnn.py:82-91): [B, k, C], rows ordered by key descending."""
+    lib = _lib.load()
+    z = _ops._c(z, torch.float32)
+    key = _ops._c(key, torch.float32)
+    B = node_off.numel() - 1
+    out = torch.empty((B, k, z.shape[1]), dtype=torch.float32, device=z.device)
+    _lib.check(lib.lpg_seal_sortpool_f32(_ops._ptr(z), z.stride(0), _ops._ptr(key), _ops._ptr(node_off), B, k,
+                                         z.shape[1], _ops._ptr(out), _ops._stream()), "seal_sortpool")
+    return out
+
+
+def head(z, key, node_off, hw):
+    """The DGCNN head of SEAL/model/gnn.py:82-137, batched over all subgraphs:
+    SortPooling -> conv1d(96->16, stride 96) -> conv1d(width 5, 16->32) -> dense 128 relu -> dense 2
+    -> softmax.  Every stage is one launch on the whole batch; the two 1-D convolutions are matmuls
+    over (overlapping) row windows of the previous buffer, so nothing is gathered or copied.
+    hw: dict with conv1d_kernel_1 [96,1,16], conv1d_kernel_2 [5,16,32], weight_1 [448,128], bias_1,
+    weight_2 [128,2], bias_2 (the shipped checkpoint's tensors).  Returns (pre_y [B,2], score [B])."""
+    lib = _lib.load()
+    k1 = hw["conv1d_kernel_1"].reshape(-1, hw["conv1d_kernel_1"].shape[-1])          # [96, 16]
+    k2 = hw["conv1d_kernel_2"].reshape(-1, hw["conv1d_kernel_2"].shape[-1])          # [80, 32] (dt-major)
+    fw, c1, c2 = hw["conv1d_kernel_2"].shape
+    k = hw["weight_1"].shape[0] // c2 + fw - 1                                           # threshold_k (18)
+    B = node_off.numel() - 1
+    pooled = sortpool(z, key, node_off, k)                                               # [B, k, 96]
+    a = _ops.linear(pooled.view(B * k, -1), k1, w_is_km=True)                            # [B*k, 16]
+    c = torch.zeros((B * k, c2), dtype=torch.float32, device=z.device)
+    _ops.linear(a, k2, w_is_km=True, n=B * k - (fw - 1), ldx=c1, out=c[: B * k - (fw - 1)])   # windows t..t+4
+    dense = _ops.linear(c, hw["weight_1"], hw["bias_1"], w_is_km=True, act="relu", n=B, ldx=k * c2)
+    pre_y = _ops.linear(dense, hw["weight_2"], hw["bias_2"], w_is_km=True)
+    score = torch.empty(B, dtype=torch.float32, device=z.device)
+    _lib.check(lib.lpg_softmax2_pos_score_f32(_ops._ptr(pre_y), B, _ops._ptr(score), _ops._stream()), "softmax2")
+    return pre_y, score
+
+
+def score_links(positive, negative, nodes_size, emb, weights, head_weights, test_ratio=0.1, hop=1, device="cuda"):
+    """the SEAL scoring forward end to end for a candidate set: structure (a10-a12), graph
+    convolutions (a9) and the head.  Returns (scores [B], labels [B,1], batch)."""
+    batch, labels, T, tag_map, _ = link2subgraph(positive, negative, nodes_size, test_ratio, hop, device=device)
+    g, d_inv, x = gnn_inputs(batch, tag_map, T, emb)
+    z, key = graph_conv_stack(g, d_inv, x, weights)
+    _, score = head(z, key, batch.node_off(), head_weights)
+    return score, labels, batch

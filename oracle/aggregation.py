@@ -188,3 +188,26 @@ def auc(y_true, score):
         i = j + 1
     npos, nneg = y.sum(), (~y).sum()
     return (ranks[y].sum() - npos * (npos + 1) / 2.0) / (npos * nneg)
+
+
+def seal_head(z, key, hw):
+    """SEAL/model/gnn.py:82-137 on ONE subgraph, fp64 (PARITY UNPINNED: TensorFlow absent).
+    z = concat(Z1,Z2,Z3) [n,96], key = Z4[:,0]; hw = dict of the checkpoint's head weights.
+    SortPooling: tf.nn.top_k(key, n) order (descending, ties -> lower index), first k rows, zero pad;
+    conv1d(96 -> 16, stride 96) == per-row matmul; conv1d(width 5, 16 -> 32, VALID); flatten;
+    relu(x W1 + b1); x W2 + b2; softmax -> P(class 1)."""
+    z = np.asarray(z, dtype=np.float64)
+    key = np.asarray(key, dtype=np.float64)
+    w1 = np.asarray(hw["weight_1"], dtype=np.float64)
+    k = w1.shape[0] // 32 + 4
+    order = np.lexsort((np.arange(len(key)), -key))            # key descending, index ascending
+    pooled = np.zeros((k, z.shape[1]))
+    m = min(k, len(key))
+    pooled[:m] = z[order[:m]]
+    a = pooled @ np.asarray(hw["conv1d_kernel_1"], dtype=np.float64).reshape(96, 16)
+    k2 = np.asarray(hw["conv1d_kernel_2"], dtype=np.float64)    # [5, 16, 32]
+    b = np.stack([sum(a[t + dt] @ k2[dt] for dt in range(5)) for t in range(k - 4)])
+    dense = np.maximum(b.reshape(-1) @ w1 + np.asarray(hw["bias_1"], dtype=np.float64), 0.0)
+    pre_y = dense @ np.asarray(hw["weight_2"], dtype=np.float64) + np.asarray(hw["bias_2"], dtype=np.float64)
+    e = np.exp(pre_y - pre_y.max())
+    return pre_y, float(e[1] / e.sum())

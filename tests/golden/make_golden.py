@@ -229,12 +229,16 @@ def gen_seal_weights():
     path = os.path.join(REF, "SEAL/model/model-1000.data-00000-of-00001")
     raw = np.fromfile(path, dtype=np.uint8)
     spec = {"graph_weight_1": ((106, 32), 50724), "graph_weight_2": ((32, 32), 91428),
-            "graph_weight_3": ((32, 32), 103716), "graph_weight_4": ((32, 1), 116004)}
+            "graph_weight_3": ((32, 32), 103716), "graph_weight_4": ((32, 1), 116004),
+            # the head (SEAL/model/gnn.py:103-137): conv1d kernels, dense layers
+            "conv1d_kernel_1": ((96, 1, 16), 0), "conv1d_kernel_2": ((5, 16, 32), 18432),
+            "bias_1": ((128,), 49164), "bias_2": ((2,), 50700),
+            "weight_1": ((448, 128), 116132), "weight_2": ((128, 2), 804260)}
     out = {}
     for k, (shape, off) in spec.items():
         nb = int(np.prod(shape)) * 4
         w = raw[off:off + nb].view("<f4").reshape(shape).copy()
-        assert np.isfinite(w).all() and 1e-3 < np.abs(w).mean() < 1.0, (k, np.abs(w).mean())
+        assert np.isfinite(w).all() and 1e-4 < np.abs(w).mean() < 2.0, (k, np.abs(w).mean())
         out[k] = w
         print(f"[weights] {k}: {shape} mean|w|={np.abs(w).mean():.4f}")
     np.savez_compressed(os.path.join(HERE, "seal_weights.npz"), **out)
