@@ -177,14 +177,17 @@ int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8
  * (adj_rowptr[n+1], adj_col sorted ascending per row, self loops allowed)
  * [SEAL/config/subgraph.py:105-141, SEAL/utils/utils.py:35-54].
  * Per candidate pair b (pairs is [B,2]): nodes[b, 0:n_b] = [u, v, rest ascending]; capped[b] = 1
- * when the reference's RNG-dependent 100-node truncation would trigger (then the caller supplies
- * the node list: replay != 0 makes the kernel take nodes/n_nodes as INPUT).
+ * when the reference's RNG-dependent 100-node truncation (np.random.shuffle, :122,128) would
+ * trigger in either visiting order.  cap_policy 0: such pairs come back with n = 0 and the caller
+ * supplies the node list (replay != 0 makes the kernel take nodes/n_nodes as INPUT -- how tests
+ * replay the reference's own lists); cap_policy 1: the kernel follows the same branch with a
+ * counter-based hash of (seed, b) in place of the RNG (visiting order, kept neighbours).
  * tags[b, i] = DRNL tag (raw, before the global compaction); adjacency is returned as a bit
  * matrix adj_bits[b, i, w] (uint32 words, MAXN/32 words per row), target entries cleared. */
 #define LPG_SEAL_MAXN 128
 int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
                        const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
-                       int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits,
+                       int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits,
                        uint8_t* capped, int32_t* err_flag, void* stream);
 /* Block-diagonal CSR of A~ = A + I over a batch, D^-1 = 1/rowsum(A~), and
  * X = [onehot(tag_map[tag], T) || emb[node]]  [SEAL/config/data.py:94-140].

@@ -64,9 +64,43 @@ __device__ void bfs_bits(const uint32_t (*adj)[WORDS], int n, int src, int* dist
   }
 }
 
+struct ListPlan {
+  int32_t node;     // whose neighbour list
+  int count;        // entries taken from it
+  int64_t deg;      // its degree
+  uint64_t a, b;    // entry i is neighbour (a*i + b) mod deg  (identity for a full list)
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {   // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ int64_t gcd64(int64_t x, int64_t y) {
+  while (y) { const int64_t r = x % y; x = y; y = r; }
+  return x;
+}
+
+// `m` distinct neighbours of `node` in a pseudo-random order: an affine permutation of [0, deg)
+__device__ ListPlan truncated_list(int32_t node, int64_t deg, int m, uint64_t h) {
+  ListPlan L{node, 0, deg, 1, 0};
+  if (deg <= 0 || m <= 0) return L;
+  L.count = static_cast<int>(m < deg ? m : deg);
+  if (L.count > MAXN) L.count = MAXN;
+  if (deg > 1) {
+    int64_t a = 1 + static_cast<int64_t>(h % static_cast<uint64_t>(deg - 1));
+    while (gcd64(a, deg) != 1) a = a % (deg - 1) + 1;
+    L.a = static_cast<uint64_t>(a);
+    L.b = mix64(h) % static_cast<uint64_t>(deg);
+  }
+  return L;
+}
+
 __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_graph, const int64_t* __restrict__ pairs,
-    int64_t B, int hop, int max_nb, int replay, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
+    int64_t B, int hop, int max_nb, int replay, int cap_policy, uint64_t seed, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
     int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag) {
   __shared__ int32_t cand[2 * MAXN];
   __shared__ int32_t nodes[MAXN];
@@ -74,6 +108,7 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
   __shared__ int dist0[MAXN], dist1[MAXN];
   __shared__ uint32_t vis[WORDS], fr[WORDS], nx[WORDS];
   __shared__ int s_n, s_capped;
+  __shared__ ListPlan s_list[2];
   const int t = threadIdx.x;
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
@@ -103,62 +138,102 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
       if (t == 0) s_n = n;
       __syncthreads();
     } else {
-      // ---- node set: {u, v} U N(u) U N(v), the reference's cap rule (subgraph.py:123-130)
+      // ---- node set: {u, v} U N(u) U N(v) with the reference's cap rule (subgraph.py:118-135)
       if (t == 0) {
         // The reference visits the two targets in a SHUFFLED order (:122); the truncation branch
-        // fires when len(sub) + len(neighbours) >= max_neighbors at either visit.  `capped` is
-        // set when it would fire in either order, so the uncapped result is order-free.
+        // (:124-130) fires when len(sub) + len(neighbours) >= max_neighbors at a visit.  `capped` is
+        // reported when it would fire in EITHER order, so an uncapped result is order- and RNG-free.
         const int size0 = (u == v) ? 1 : 2;
-        int cap = 0;
+        const int64_t bu = rowptr[u], du = rowptr[u + 1] - bu;
+        const int64_t bv = rowptr[v], dv = rowptr[v + 1] - bv;
+        int cap = 0, eu = 0, ev = 0;
         if (hop >= 1) {
-          const int64_t bu = rowptr[u], du = rowptr[u + 1] - bu;
-          const int64_t bv = rowptr[v], dv = rowptr[v + 1] - bv;
           if (size0 + du >= max_nb || size0 + dv >= max_nb) {
             cap = 1;
           } else {
-            int eu = 0, ev = 0;   // |N(x) \ {u, v}|
             for (int64_t k = 0; k < du; ++k) { const int32_t x = col[bu + k]; eu += (x != u && x != v); }
             for (int64_t k = 0; k < dv; ++k) { const int32_t x = col[bv + k]; ev += (x != u && x != v); }
             if (size0 + eu + dv >= max_nb || size0 + ev + du >= max_nb) cap = 1;
           }
         }
         s_capped = cap;
+        // plan the two neighbour lists: (node, count, affine permutation a*i+b mod deg)
+        s_list[0] = s_list[1] = ListPlan{-1, 0, 0, 1, 0};
+        if (hop >= 1 && !(cap && cap_policy == 0)) {
+          if (!cap) {
+            s_list[0] = ListPlan{u, static_cast<int>(du), du, 1, 0};
+            if (u != v) s_list[1] = ListPlan{v, static_cast<int>(dv), dv, 1, 0};
+          } else {
+            // deterministic stand-in for np.random.shuffle: visiting order and the kept neighbours
+            // come from a counter-based hash of (seed, pair index)
+            const uint64_t h = mix64(seed ^ (static_cast<uint64_t>(b) * 0x9E3779B97F4A7C15ull));
+            const bool swap = (h >> 63) != 0;
+            const int32_t first = swap ? v : u, second = swap ? u : v;
+            const int64_t d1 = swap ? dv : du, d2 = swap ? du : dv;
+            int size = size0;
+            if (size + d1 < max_nb) {
+              s_list[0] = ListPlan{first, static_cast<int>(d1), d1, 1, 0};
+              const int64_t b1 = swap ? bv : bu;
+              int e1 = 0;
+              for (int64_t k = 0; k < d1; ++k) { const int32_t x = col[b1 + k]; e1 += (x != u && x != v); }
+              size += e1;
+              if (u != v) {
+                if (size + d2 < max_nb)
+                  s_list[1] = ListPlan{second, static_cast<int>(d2), d2, 1, 0};
+                else
+                  s_list[1] = truncated_list(second, d2, max_nb - size, mix64(h + 1));
+              }
+            } else {
+              s_list[0] = truncated_list(first, d1, max_nb - size, mix64(h + 2));   // then `break` (:130)
+            }
+          }
+        }
       }
       __syncthreads();
-      if (s_capped) {                               // RNG-dependent in the reference: caller replays
+      if (s_capped && cap_policy == 0) {             // RNG-dependent in the reference: caller replays
         if (t == 0) { n_out[b] = 0; capped_out[b] = 1; }
         continue;
       }
-      int n_c = 0;
-      if (hop >= 1) {
-        const int64_t bu = rowptr[u], bv = rowptr[v];
-        const int du = static_cast<int>(rowptr[u + 1] - bu), dv = static_cast<int>(rowptr[v + 1] - bv);
-        // candidates: N(u) \ {u,v}, then N(v) \ ({u,v} U N(u)); marked -1 when dropped
-        for (int i = t; i < du; i += kSealBlock) {
-          const int32_t x = col[bu + i];
-          cand[i] = (x == u || x == v) ? -1 : x;
-        }
-        if (u != v)
-          for (int i = t; i < dv; i += kSealBlock) {
-            const int32_t x = col[bv + i];
-            cand[du + i] = (x == u || x == v || row_has(col + bu, du, x)) ? -1 : x;
-          }
-        n_c = du + (u != v ? dv : 0);
+      const int cA = s_list[0].count, cB = s_list[1].count;
+      const int n_c = cA + cB;                        // <= 2 * MAXN by construction
+      for (int i = t; i < n_c; i += kSealBlock) {
+        const ListPlan& L = i < cA ? s_list[0] : s_list[1];
+        const int64_t k = i < cA ? i : i - cA;
+        const int64_t idx = (L.a * static_cast<uint64_t>(k) + L.b) % static_cast<uint64_t>(L.deg);
+        const int32_t x = col[rowptr[L.node] + static_cast<int64_t>(idx)];
+        cand[i] = (x == u || x == v) ? -1 : x;
       }
       __syncthreads();
-      // rank sort (keys unique): position = number of smaller kept keys
-      for (int i = t; i < n_c; i += kSealBlock) {
-        const int32_t x = cand[i];
-        if (x >= 0) {
+      // drop duplicates (keep the first occurrence), then rank sort the survivors
+      int32_t mine[2];
+      bool keep[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = t + q * kSealBlock;
+        mine[q] = i < n_c ? cand[i] : -1;
+        keep[q] = mine[q] >= 0;
+        if (keep[q])
+          for (int j = 0; j < i; ++j)
+            if (cand[j] == mine[q]) { keep[q] = false; break; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = t + q * kSealBlock;
+        if (i < n_c && !keep[q]) cand[i] = -1;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (keep[q]) {
           int rank = 0;
-          for (int j = 0; j < n_c; ++j) { const int32_t y = cand[j]; rank += (y >= 0 && y < x); }
-          nodes[2 + rank] = x;
+          for (int j = 0; j < n_c; ++j) { const int32_t y = cand[j]; rank += (y >= 0 && y < mine[q]); }
+          if (2 + rank < MAXN) nodes[2 + rank] = mine[q];
           atomicAdd(&s_n, 1);
         }
-      }
       if (t == 0) { nodes[0] = u; nodes[1] = v; }
       __syncthreads();
-      if (t == 0) s_n += 2;
+      if (t == 0) s_n = (s_n + 2 > MAXN) ? MAXN : s_n + 2;
       __syncthreads();
     }
     const int n = s_n;
@@ -166,6 +241,7 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
       if (t == 0) { n_out[b] = 0; capped_out[b] = replay ? 0 : 1; }
       continue;
     }
+    const int was_capped = replay ? 0 : s_capped;
 
     // ---- induced adjacency: bit (i, j) = A[nodes[i], nodes[j]], target entries cleared (:136-137)
     for (int p = t; p < n * n; p += kSealBlock) {
@@ -204,7 +280,7 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
 #pragma unroll
       for (int w = 0; w < WORDS; ++w) adj_out[(b * MAXN + t) * WORDS + w] = t < n ? adj[t][w] : 0u;
     }
-    if (t == 0) { n_out[b] = n; capped_out[b] = 0; }
+    if (t == 0) { n_out[b] = n; capped_out[b] = static_cast<uint8_t>(was_capped); }
   }
 }
 
@@ -346,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void softmax2_kernel(const float* __restric
 
 LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
                                   const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
-                                  int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits, uint8_t* capped,
+                                  int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits, uint8_t* capped,
                                   int32_t* err_flag, void* stream) {
   LPG_REQUIRE(B >= 0 && n_graph_nodes >= 0, "seal_subgraphs: bad sizes");
   LPG_REQUIRE(hop == 0 || hop == 1, "seal_subgraphs: hop must be 0 or 1 (the reference itself fails for hop >= 2)");
@@ -355,7 +431,7 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   LPG_REQUIRE(adj_rowptr && pairs && nodes && n_nodes && tags && adj_bits && capped, "seal_subgraphs: null pointer");
   const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
   hipLaunchKernelGGL(seal_subgraph_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), adj_rowptr, adj_col,
-                     n_graph_nodes, pairs, B, hop, max_neighbors, replay, nodes, n_nodes, tags, adj_bits, capped, err_flag);
+                     n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag);
   return check_launch("seal_subgraphs");
 }
 

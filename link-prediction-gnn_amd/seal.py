@@ -51,10 +51,18 @@ class SubgraphBatch:
         return off
 
 
-def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, replay_n=None):
-    """Batched extract_subgraph + node_labeling.  pairs int64 [B,2].  Pairs for which the
-    reference's RNG-dependent truncation would fire come back with capped=1 and n=0; pass their
-    node lists through replay_nodes/replay_n to label them in a given order."""
+CAP_POLICY = {"report": 0, "device": 1}
+
+
+def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, replay_n=None, cap_policy="device",
+                      seed=0):
+    """Batched extract_subgraph + node_labeling.  pairs int64 [B,2].  `capped` marks the pairs for
+    which the reference's RNG-dependent truncation (np.random.shuffle, subgraph.py:122,128) fires:
+      cap_policy="device": the kernel follows the same branch with a hash of (seed, pair index) in
+                           place of the RNG -- deterministic, no host round trip;
+      cap_policy="report": those pairs come back with n = 0; pass node lists through
+                           replay_nodes / replay_n to label them in a given order (tests replay the
+                           reference's own lists this way)."""
     lib = _lib.load()
     dev = graph.rowptr.device
     pairs = torch.as_tensor(pairs, dtype=torch.int64, device=dev).contiguous()
@@ -72,7 +80,8 @@ def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, r
     adj_bits = torch.empty((B, MAXN, MAXN // 32), dtype=torch.int32, device=dev)
     capped = torch.empty(B, dtype=torch.uint8, device=dev)
     _lib.check(lib.lpg_seal_subgraphs(_ops._ptr(graph.rowptr), _ops._ptr(graph.col), graph.n_nodes, _ops._ptr(pairs),
-                                      B, int(hop), int(max_neighbors), int(replay), _ops._ptr(nodes), _ops._ptr(n),
+                                      B, int(hop), int(max_neighbors), int(replay), CAP_POLICY[cap_policy],
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, _ops._ptr(nodes), _ops._ptr(n),
                                       _ops._ptr(tags), _ops._ptr(adj_bits), _ops._ptr(capped),
                                       _ops._ptr(_ops.err_flag(dev)), _ops._stream()), "seal_subgraphs")
     _ops.maybe_check(dev, "candidate pair / node id")
@@ -147,10 +156,12 @@ def auto_hop(positive, negative, graph, test_ratio=0.1):
 
 
 def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=0, max_neighbors=100, seed=0,
-                  device="cuda"):
-    """SEAL/config/subgraph.py:11-102 for hop in {0, 1}: negatives first, then positives (:74).
+                  device="cuda", cap_policy="device"):
+    """SEAL/config/subgraph.py:11-102 for hop in {0, 1, "auto"}: negatives first, then positives (:74).
     Returns (batch, labels, tags_size, tag_map, graph).  Tags in `batch.tags` are RAW; tag_map is
-    the global compaction (:84-101) applied when features are built."""
+    the global compaction (:84-101) applied when features are built.
+    cap_policy: "device" (default) or "host" -- the few pairs that hit the 100-node cap are rebuilt
+    on the host with a seeded numpy RandomState walking the reference's own branch, then replayed."""
     if network_type != 0:
         raise NotImplementedError("the reference is run undirected (network_type=0)")
     graph = build_train_csr(positive, nodes_size, test_ratio, device)
@@ -160,20 +171,23 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
             raise NotImplementedError("the heuristic selected hop=2, which the reference itself cannot run "
                                       "(SEAL/config/subgraph.py:122,131 shuffles a set)")
     pairs = np.concatenate([np.asarray(negative), np.asarray(positive)]).astype(np.int64)
-    batch = extract_subgraphs(pairs, graph, hop, max_neighbors)
-    capped = batch.capped.bool()
-    if bool(capped.any()):
-        idx = torch.nonzero(capped).reshape(-1).cpu().numpy()
-        rp, cl = graph.rowptr.cpu().numpy(), graph.col.cpu().numpy()
-        rng = np.random.RandomState(seed)
-        lists = [_host_capped_nodes(pairs[i], rp, cl, max_neighbors, rng) for i in idx]
-        rn = np.full((len(idx), MAXN), -1, dtype=np.int32)
-        for k, l in enumerate(lists):
-            rn[k, : len(l)] = l
-        sub = extract_subgraphs(pairs[idx], graph, hop, max_neighbors, replay_nodes=rn,
-                                replay_n=np.asarray([len(l) for l in lists], dtype=np.int32))
-        ii = torch.as_tensor(idx, device=batch.n.device)
-        batch.nodes[ii], batch.n[ii], batch.tags[ii], batch.adj_bits[ii] = sub.nodes, sub.n, sub.tags, sub.adj_bits
+    if cap_policy == "device":
+        batch = extract_subgraphs(pairs, graph, hop, max_neighbors, cap_policy="device", seed=seed)
+    else:
+        batch = extract_subgraphs(pairs, graph, hop, max_neighbors, cap_policy="report")
+        capped = batch.capped.bool()
+        if bool(capped.any()):
+            idx = torch.nonzero(capped).reshape(-1).cpu().numpy()
+            rp, cl = graph.rowptr.cpu().numpy(), graph.col.cpu().numpy()
+            rng = np.random.RandomState(seed)
+            lists = [_host_capped_nodes(pairs[i], rp, cl, max_neighbors, rng) for i in idx]
+            rn = np.full((len(idx), MAXN), -1, dtype=np.int32)
+            for k, l in enumerate(lists):
+                rn[k, : len(l)] = l
+            sub = extract_subgraphs(pairs[idx], graph, hop, max_neighbors, replay_nodes=rn,
+                                    replay_n=np.asarray([len(l) for l in lists], dtype=np.int32))
+            ii = torch.as_tensor(idx, device=batch.n.device)
+            batch.nodes[ii], batch.n[ii], batch.tags[ii], batch.adj_bits[ii] = sub.nodes, sub.n, sub.tags, sub.adj_bits
     labels = torch.cat([torch.zeros(len(negative), dtype=torch.uint8), torch.ones(len(positive), dtype=torch.uint8)])
     tag_map, tags_size = compact_tag_map(batch)
     return batch, labels.reshape(-1, 1), tags_size, tag_map, graph

@@ -398,7 +398,7 @@ def test_seal_subgraphs_golden(dev, sl, hop):
     off, nodes_ref, tags_ref = sl[k + "off"], sl[k + "nodes"], sl[k + "tags"]
     graph = seal.build_train_csr(pos, 620, 0.1, dev)
     pairs = np.concatenate([neg, pos])
-    batch = seal.extract_subgraphs(pairs, graph, hop)
+    batch = seal.extract_subgraphs(pairs, graph, hop, cap_policy="report")
     n, capped = _np(batch.n), _np(batch.capped).astype(bool)
     nodes, tags, bits = _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits)
     ref_n = np.diff(off)
@@ -602,3 +602,41 @@ def test_seal_head_with_reference_weights(dev, sl, golden_dir):
     assert torch.equal(s2, score)
     y = _np(lab).reshape(-1)
     assert 0.0 <= agg.auc(y, _np(s2)) <= 1.0
+
+
+def test_seal_capped_pairs_device_policy(dev, sl):
+    """pairs that hit the reference's RNG-dependent 100-node truncation: the on-device policy must
+    produce a valid outcome of that branch (u, v kept; the rest a subset of N(u) U N(v); size within
+    the cap; canonical order), be deterministic, and label/induce it exactly like the oracle."""
+    from lpgnn_amd import seal
+    from oracle import seal_int
+    pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
+    graph = seal.build_train_csr(pos, 620, 0.1, dev)
+    pairs = np.concatenate([neg, pos])
+    A = seal_int.build_train_adjacency(pos, 620)
+    b1 = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=7)
+    b2 = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=7)
+    b3 = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=8)
+    rep = seal.extract_subgraphs(pairs, graph, 1, cap_policy="report")
+    capped = _np(b1.capped).astype(bool)
+    assert np.array_equal(capped, _np(rep.capped).astype(bool)) and capped.sum() > 0
+    assert torch.equal(b1.nodes, b2.nodes) and torch.equal(b1.tags, b2.tags) and torch.equal(b1.n, b2.n)
+    un = ~capped                                          # uncapped pairs do not depend on policy or seed
+    assert torch.equal(b1.nodes[torch.from_numpy(un).to(dev)], rep.nodes[torch.from_numpy(un).to(dev)])
+    assert torch.equal(b1.nodes[torch.from_numpy(un).to(dev)], b3.nodes[torch.from_numpy(un).to(dev)])
+    assert not torch.equal(b1.nodes, b3.nodes)            # the seed matters only where the cap bites
+    n, nodes, tags, bits = _np(b1.n), _np(b1.nodes), _np(b1.tags), _np(b1.adj_bits)
+    for g in np.nonzero(capped)[0]:
+        u, v = int(pairs[g, 0]), int(pairs[g, 1])
+        nd = nodes[g, : n[g]]
+        assert 2 <= n[g] <= 100 and nd[0] == u and nd[1] == v
+        rest = nd[2:]
+        assert np.all(np.diff(rest) > 0)                  # ascending, no duplicates
+        cand = set(seal_int.neighbours(A, u)) | set(seal_int.neighbours(A, v))
+        assert set(rest.tolist()) <= cand - {u, v}
+        adj = seal_int.induced_adjacency(nd, A)
+        assert np.array_equal(_unpack_adj(bits[g], int(n[g])), adj)
+        assert tags[g, : n[g]].tolist() == seal_int.node_labeling(adj)
+    # the host policy walks the reference's branch with a numpy RandomState: same validity
+    hb, _, T, _, _ = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev, cap_policy="host", seed=3)
+    assert int(hb.n.max()) <= 100 and int(hb.n.min()) >= 2
