@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restric
 
 inline int part_blocks(int64_t n, int64_t* rows_per_block) {
   int64_t rpb = ceil_div(n, kMaxPartBlocks);
-  if (rpb < 64) rpb = 64;
+  if (rpb < 8) rpb = 8;           // small n: many short blocks (each thread's row loop is a latency chain)
   *rows_per_block = rpb;
   return static_cast<int>(ceil_div(n, rpb));
 }

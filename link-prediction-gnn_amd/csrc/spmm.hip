@@ -209,19 +209,35 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
   const bool wave_full = __all(n_e == kChunk);      // only the last wave has a ragged tail
   const int gshift = lane & ~(G - 1);
 
+  // index words (column, row id, next row id, weight) of one G-edge batch; with PREFETCH the
+  // next batch's words are requested before the current batch's gathers, so the gather of batch
+  // b+1 never waits on an index round trip (one wave per SIMD: nobody else hides that latency)
+  constexpr bool PREFETCH = (MODE & 1) != 0;
+  auto load_idx = [&](int base, int& c, int& r, int& rn, float& w) {
+    const bool in = base + gl < n_e;
+    const int64_t e = start + base + gl;
+    c = in ? a.col[e] : 0;
+    r = in ? a.rowid[e] : -1;
+    rn = (in && e + 1 < E) ? a.rowid[e + 1] : -2;
+    w = 0.f;
+    if constexpr (WEIGHTED) w = in ? a.val[e] : 0.f;
+  };
+  int c, r, rn, c_n = 0, r_n = -1, rn_n = -2;
+  float w, w_n = 0.f;
+  load_idx(0, c, r, rn, w);
+
 #pragma unroll 1
   for (int base = 0; base < kChunk; base += G) {
     if (!__any(base < n_e)) break;
+    if constexpr (PREFETCH) {
+      if (base + G < kChunk) load_idx(base + G, c_n, r_n, rn_n, w_n);
+    } else if (base > 0) {
+      load_idx(base, c, r, rn, w);
+    }
     const bool in = base + gl < n_e;
-    const int64_t e = start + base + gl;
-    const int c = in ? a.col[e] : 0;
-    const int r = in ? a.rowid[e] : -1;
-    const int rn = (in && e + 1 < E) ? a.rowid[e + 1] : -2;
     const bool fl = in && r != rn;                   // a row ends at this lane's edge
     const unsigned long long fmask = __ballot(fl);   // wave-uniform: one bit per (group, step)
     const unsigned long long mym = fmask >> gshift;  // this group's bits at [0, G)
-    float w = 0.f;
-    if constexpr (WEIGHTED) w = in ? a.val[e] : 0.f;
 
 #pragma unroll 1
     for (int j0 = 0; j0 < G; j0 += U) {
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
         raw[u] = Piece<T, VEC>::load(xb + static_cast<int64_t>(cj) * a.ldx);
       }
       const bool any_flush = (fmask & (rep << j0)) != 0ull;      // scalar test
-      if (MODE == 2 || (wave_full && !any_flush)) {
+      if ((MODE & 2) != 0 || (wave_full && !any_flush)) {
         // fast path (most sub-batches): no row ends here in any group -> straight accumulate
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -277,6 +293,7 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
         }
       }
     }
+    if constexpr (PREFETCH) { c = c_n; r = r_n; rn = rn_n; w = w_n; }
   }
   if (open_right && lane_on) carry_store<VEC>(carry0 + ((first_seg && open_left) ? 0 : a.dpad), acc);
 }
@@ -368,6 +385,8 @@ int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
   hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, W, EP, 8, MD>), grid, blk, lds, st, a)
   if (tn.mode == 2 && !a.val && !epi) {
     LPG_LAUNCH_MAIN(false, false, 2);          // debug: gather-only upper bound (wrong results)
+  } else if (tn.mode == 1 && !a.val && !epi) {
+    LPG_LAUNCH_MAIN(false, false, 1);          // index prefetch variant
   } else if (a.val) {
     if (epi) LPG_LAUNCH_MAIN(true, true, 0); else LPG_LAUNCH_MAIN(true, false, 0);
   } else {

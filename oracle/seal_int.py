@@ -23,7 +23,10 @@ def build_train_adjacency(positive, n_nodes, test_ratio=0.1):
 
 def neighbours(A, node):
     """nx.neighbors on the Graph built from train_pos == nonzero columns of row `node`
-    (a self loop lists the node itself)."""
+    (a self loop lists the node itself).  A: dense uint8 [N,N] or a scipy.sparse CSR matrix
+    (large synthetic graphs)."""
+    if hasattr(A, "indptr"):
+        return np.sort(A.indices[A.indptr[node]:A.indptr[node + 1]])
     return np.nonzero(A[node])[0]
 
 
@@ -62,7 +65,10 @@ def enclosing_nodes(node_pair, A, hop, max_neighbors=100):
 def induced_adjacency(nodes, A):
     """SEAL/config/subgraph.py:136-137 -- A[nodes][:, nodes] with the target entries cleared."""
     nodes = np.asarray(nodes, dtype=np.int64)
-    adj = A[nodes, :][:, nodes].copy()
+    if hasattr(A, "indptr"):
+        adj = (A[nodes, :][:, nodes].toarray() != 0).astype(np.uint8)
+    else:
+        adj = A[nodes, :][:, nodes].copy()
     adj[0, 1] = adj[1, 0] = 0
     return adj
 

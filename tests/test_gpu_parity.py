@@ -640,3 +640,44 @@ def test_seal_capped_pairs_device_policy(dev, sl):
     # the host policy walks the reference's branch with a numpy RandomState: same validity
     hb, _, T, _, _ = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev, cap_policy="host", seed=3)
     assert int(hb.n.max()) <= 100 and int(hb.n.min()) >= 2
+
+
+def test_seal_subgraphs_collab_scale_synthetic(dev):
+    """configs[2] stand-in: RMAT |V| = 235 868, 1 285 465 undirected edges
+    (seed 1), random candidate pairs (seed 2), 1-hop subgraphs capped at 100: every pair against
+    the oracle on a scipy CSR adjacency -- node sets, adjacency and DRNL tags bit-exact for
+    uncapped pairs; capped pairs (hubs with thousands of neighbours) valid under the device policy."""
+    import scipy.sparse as sp
+    import bench
+    from lpgnn_amd import seal
+    from oracle import seal_int
+    N, E = 235_868, 1_285_465
+    ei = bench.rmat_edges(N, E, 1, dev)
+    und = ei.t().cpu().numpy()
+    graph = seal.build_train_csr(und, N, test_ratio=0.0, device=dev)
+    rp, cl = _np(graph.rowptr), _np(graph.col)
+    A = sp.csr_matrix((np.ones(cl.size, dtype=np.uint8), cl, rp), shape=(N, N))
+    assert (A != A.T).nnz == 0
+    rng = np.random.default_rng(2)
+    pairs = rng.integers(0, N, size=(1500, 2))
+    hubs = np.argsort(np.diff(rp))[-40:]
+    pairs[:40, 0] = hubs                                        # force the cap on some pairs
+    pairs[40:60] = und[rng.integers(0, E, 20)]                  # and some true edges
+    batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=11)
+    n, nodes, tags, bits, capped = _np(batch.n), _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits), _np(batch.capped)
+    assert capped[:40].all() and int(np.diff(rp).max()) > 1000
+    n_unc = 0
+    for g, (u, v) in enumerate(pairs):
+        want_nodes, want_cap = seal_int.enclosing_nodes((u, v), A, 1)
+        assert bool(capped[g]) == want_cap
+        nd = nodes[g, : n[g]]
+        if not want_cap:
+            n_unc += 1
+            assert nd.tolist() == want_nodes
+        else:
+            cand = set(seal_int.neighbours(A, u).tolist()) | set(seal_int.neighbours(A, v).tolist())
+            assert nd[0] == u and nd[1] == v and n[g] <= 100 and set(nd[2:].tolist()) <= cand - {u, v}
+        adj = seal_int.induced_adjacency(nd, A)
+        assert np.array_equal(_unpack_adj(bits[g], int(n[g])), adj)
+        assert tags[g, : n[g]].tolist() == seal_int.node_labeling(adj)
+    assert n_unc > 1000
