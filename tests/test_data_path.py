@@ -1,0 +1,37 @@
+"""CPU: the host-side data path.  random_split_edges draws from the torch CPU RNG
+in the reference's order, so under the same seed it must reproduce the reference's split bit for bit
+(golden: tests/golden/twowl_int.npz `split_*`, produced by TwoWL/utils.py::random_split_edges)."""
+import os
+
+import numpy as np
+import torch
+
+from lpgnn_amd import data, twowl
+
+
+def test_random_split_edges_matches_reference(golden_dir):
+    tw = np.load(os.path.join(golden_dir, "twowl_int.npz"))
+    ei = data.load_edges(os.path.join(golden_dir, "fb-pages-food.edges"))
+    assert ei.shape == (2, 2102) and int(ei.max()) == 619
+    torch.manual_seed(0)
+    sp = data.random_split_edges(ei, 620, 0.05, 0.1)
+    for k in ("train_pos", "val_pos", "test_pos", "val_neg", "test_neg"):
+        assert np.array_equal(sp[k].numpy(), tw["split_" + k]), k
+    assert sp["train_pos"].shape[1] == 1644 and sp["val_pos"].shape[1] == 96 and sp["test_pos"].shape[1] == 193
+    assert np.array_equal(twowl.double(sp["train_pos"]).numpy(), tw["double_train_pos"])
+
+
+def test_negative_sampling_contract():
+    g = torch.Generator().manual_seed(3)
+    n = 50
+    ei = torch.randint(0, n, (2, 400), generator=g)
+    ei = torch.cat([ei, torch.arange(n).repeat(2, 1)], 1)
+    neg = data.negative_sampling(ei, n, 300, generator=g)
+    assert neg.shape == (2, 300)
+    have = set((ei[0] * n + ei[1]).tolist())
+    keys = (neg[0] * n + neg[1]).tolist()
+    assert len(set(keys)) == 300 and not (set(keys) & have)
+    assert bool((neg[0] != neg[1]).all())                 # self loops were passed in, so none are sampled
+    g2 = torch.Generator().manual_seed(3)
+    torch.randint(0, n, (2, 400), generator=g2)
+    assert torch.equal(data.negative_sampling(ei, n, 300, generator=g2), neg)      # seeded => reproducible

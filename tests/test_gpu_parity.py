@@ -681,3 +681,24 @@ def test_seal_subgraphs_collab_scale_synthetic(dev):
         assert np.array_equal(_unpack_adj(bits[g], int(n[g])), adj)
         assert tags[g, : n[g]].tolist() == seal_int.node_labeling(adj)
     assert n_unc > 1000
+
+
+def test_data_path_to_forward_fb_pages_food(dev, golden_dir):
+    """edge list -> seeded split -> BaseGraph (device get_ei2 x3, degree) -> scoring forward, against
+    the oracle's integer restatements on the same split."""
+    from lpgnn_amd import data, twowl
+    from oracle import twowl_int
+    torch.manual_seed(0)
+    bg = data.load_dataset(os.path.join(golden_dir, "fb-pages-food.edges"), device=dev)
+    bg.preprocess()
+    bg.setPosDegreeFeature()
+    assert bg.num_nodes == 620 and [e.shape[1] for e in bg.edge_indexs] == [3288, 3288, 3480]
+    for s in range(3):
+        ei, pred = _np(bg.edge_indexs[s]), _np(bg.pred_edges[s])
+        assert np.array_equal(_np(bg.ei2s[s]), twowl_int.get_ei2(620, ei, pred))
+        assert bg.pos1s[s].shape == (ei.shape[1] + pred.shape[1], 2)
+        assert np.array_equal(_np(bg.x[s]), twowl_int.degree(_np(bg.edge_indexs[min(s, 1) if s < 2 else 1]), 620))
+    x, _, ei, _, pos1, y, ei2 = bg.split(2)
+    mod = twowl.LocalWLNet(bg.max_x, channels_1wl=32, channels_2wl=16).to(dev).eval()
+    out = twowl.test_forward(mod, x, ei, pos1, y.shape[0], ei2)
+    assert out.shape == (y.shape[0] // 2, 1) and torch.isfinite(out).all()
