@@ -122,6 +122,11 @@ int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* co
 int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias,
                    int act, float* y, int64_t ldy, int64_t n, int64_t k, int64_t m, void* stream);
 
+/* bf16 storage variant (configs[2]: "d = 128, bf16"): x, w, y are bfloat16 bit patterns, products
+ * on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, bias fp32, one rounding to bf16 at the store. */
+int lpg_linear_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, int w_is_km, const float* bias,
+                    int act, uint16_t* y, int64_t ldy, int64_t n, int64_t k, int64_t m, void* stream);
+
 /* ---------------------------------------------------------------- GraphNorm (K6)
  * torch_geometric.nn.GraphNorm.forward(x, batch=None) [TwoWL/model/model.py:38,54]:
  * o = x - mean*mean_scale; y = weight*o/sqrt(mean(o^2)+eps) + bias, column-wise over all n rows;

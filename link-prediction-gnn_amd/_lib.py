@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "csrc", "liblpg_hip.so")
 
 _CTYPES = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
-    "float": ctypes.c_float, "uint8_t": ctypes.c_uint8, "uint64_t": ctypes.c_uint64,
+    "float": ctypes.c_float, "uint8_t": ctypes.c_uint8, "uint64_t": ctypes.c_uint64, "uint16_t": ctypes.c_uint16,
 }
 _PROTO = re.compile(r"^\s*(const\s+char\s*\*|int64_t|int)\s+(lpg_\w+)\s*\(([^)]*)\)\s*;", re.M | re.S)
 

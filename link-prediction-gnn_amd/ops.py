@@ -218,8 +218,10 @@ def linear(x, weight, bias=None, w_is_km=False, out=None, act=None, n=None, ldx=
     SEAL's width-5 conv1d as a matmul over a [B*k,16] buffer with ldx=16, k=80)."""
     lib = _lib.load()
     _need_gpu(x, weight, bias)
-    x = _c(x, torch.float32)
-    weight = _c(weight, torch.float32)
+    bf16 = x.dtype == torch.bfloat16                 # bf16 storage: v_mfma_f32_32x32x16_bf16, fp32 accumulate
+    dt = torch.bfloat16 if bf16 else torch.float32
+    x = _c(x, dt)
+    weight = _c(weight, dt)
     bias = _c(bias, torch.float32)
     k = weight.shape[0] if w_is_km else weight.shape[1]
     m = weight.shape[1] if w_is_km else weight.shape[0]
@@ -230,9 +232,12 @@ def linear(x, weight, bias=None, w_is_km=False, out=None, act=None, n=None, ldx=
     elif (n - 1) * ldx + k > x.numel():
         raise ValueError("linear: (n, ldx, k) window runs past the end of x")
     if out is None:
-        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
-    _lib.check(lib.lpg_linear_f32(_ptr(x), ldx, _ptr(weight), int(w_is_km), _ptr(bias), ACT[act], _ptr(out),
-                                  out.stride(0), n, k, m, _stream()), "linear_f32")
+        out = torch.empty((n, m), dtype=dt, device=x.device)
+    elif out.dtype != dt:
+        raise TypeError("linear: `out` dtype must match x")
+    fn = lib.lpg_linear_bf16 if bf16 else lib.lpg_linear_f32
+    _lib.check(fn(_ptr(x), ldx, _ptr(weight), int(w_is_km), _ptr(bias), ACT[act], _ptr(out), out.stride(0), n, k, m,
+                  _stream()), "linear")
     return out
 
 

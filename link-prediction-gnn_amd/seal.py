@@ -241,8 +241,8 @@ def graph_conv_stack(g, d_inv, x, weights):
     """SEAL/model/gnn.py:46-63: Z_l = tanh(D^-1 (A~ (Z_{l-1} W_l))), l = 1..4.
     Returns (concat(Z1, Z2, Z3) [total, 96], Z4[:, 0] -- the SortPooling key, :82)."""
     z, zs = x, []
-    for w in weights:
-        h = _ops.linear(z, w, w_is_km=True)                       # K5 on the fp32 matrix cores
+    for w in weights:                                             # x bf16 => the whole stack runs in bf16 storage
+        h = _ops.linear(z, w, w_is_km=True)                       # K5 on the matrix cores (fp32 or bf16 MFMA)
         z = g.spmm(h, row_scale=d_inv, act="tanh")                # K10: one fused kernel per layer
         zs.append(z)
     return torch.cat(zs[:3], dim=1), zs[3][:, 0]

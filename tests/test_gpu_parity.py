@@ -730,3 +730,42 @@ def test_trained_model_auc_parity_fb_pages_food(dev, golden_dir):
     assert abs(auc_ref - auc_got) <= 0.002
     assert auc_ref > 0.75, auc_ref            # the recorded reference runs span 0.79-0.89 (unseeded, 1000 epochs)
     print(f"fb-pages-food test AUC: torch reference {auc_ref:.4f}, HIP kernels {auc_got:.4f}")
+
+
+@pytest.mark.parametrize("n,k,m,km", [(620, 256, 32, False), (4252, 32, 32, False), (1000, 106, 32, True), (333, 128, 1, True),
+                                      (129, 24, 16, False), (5, 3, 2, True), (3000, 128, 128, False)])
+def test_linear_bf16_mfma(dev, n, k, m, km):
+    """bf16 storage linear: inputs rounded to bf16, fp32 accumulate, one rounding at the store."""
+    from lpgnn_amd import ops
+    rng = np.random.default_rng(n + k)
+    xt = torch.from_numpy(rng.standard_normal((n, k)).astype(np.float32)).to(dev).bfloat16()
+    wt = torch.from_numpy(rng.standard_normal((k, m) if km else (m, k)).astype(np.float32)).to(dev).bfloat16()
+    b = rng.standard_normal(m).astype(np.float32)
+    x64, w64 = _np(xt.float()).astype(np.float64), _np(wt.float()).astype(np.float64)
+    if not km:
+        w64 = w64.T
+    want = x64 @ w64 + b
+    mag = np.abs(x64) @ np.abs(w64) + np.abs(b)
+    got = _np(ops.linear(xt, wt, torch.from_numpy(b).to(dev), w_is_km=km).float()).astype(np.float64)
+    assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + TOL * mag + 1e-30)
+    got = _np(ops.linear(xt, wt, None, w_is_km=km, act="relu").float()).astype(np.float64)
+    want = np.maximum(want - b, 0)
+    assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + TOL * mag + 1e-30)
+
+
+def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
+    """configs[2] numerics: the SEAL graph-conv stack with X, weights and activations stored in
+    bf16 (fp32 accumulate everywhere) stays within bf16 rounding of the fp32 stack."""
+    from lpgnn_amd import seal
+    wz = np.load(os.path.join(golden_dir, "seal_weights.npz"))
+    gw = [torch.from_numpy(wz[f"graph_weight_{i}"]).to(dev) for i in (1, 2, 3, 4)]
+    pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
+    emb = torch.from_numpy(np.random.default_rng(0).standard_normal((620, 122)).astype(np.float32)).to(dev)
+    batch, _, T, tag_map, _ = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev)
+    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb)                      # T + 122 = 128 columns
+    assert x.shape[1] == 128
+    w1 = torch.randn(128, 32, device=dev) * 0.1
+    z32, k32 = seal.graph_conv_stack(g, d_inv, x, [w1] + gw[1:])
+    z16, k16 = seal.graph_conv_stack(g, d_inv, x.bfloat16(), [w1.bfloat16()] + [w.bfloat16() for w in gw[1:]])
+    assert z16.dtype == torch.bfloat16
+    assert float((z16.float() - z32).abs().max()) < 0.03 and float((k16.float() - k32).abs().max()) < 0.03
