@@ -76,11 +76,13 @@ int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const float* val, int
                    int64_t* rowptr, int32_t* col_out, float* val_out, int32_t* perm_out,
                    void* workspace, int64_t workspace_bytes, int32_t* err_flag, void* stream);
 
-/* gcn_norm on the dst-major CSR [PyG gcn_norm; TwoWL/model/model.py:37]:
- * deg[j] = sum of row j's weights; dinv = deg^-1/2 (inf -> 0);
- * val[k] = dinv[col[k]] * val[k] * dinv[row(k)]  (in place; val == ones when unweighted). */
-int lpg_gcn_norm_csr(const int64_t* rowptr, const int32_t* col, float* val, float* dinv,
-                     int64_t N, void* stream);
+/* gcn_norm on the dst-major CSR [PyG gcn_norm; TwoWL/model/model.py:37] (needs the plan: per-edge
+ * row ids): deg[j] = sum of row j's weights; dinv = deg^-1/2 (inf -> 0);
+ * val[k] = dinv[col[k]] * val[k] * dinv[row(k)], edge-parallel, in place.
+ * unit_weights != 0: every weight is 1 (edge_weight=None): `val` is output only and deg is the row
+ * length. */
+int lpg_gcn_norm_csr(const void* plan, const int64_t* rowptr, const int32_t* col, float* val,
+                     float* dinv, int64_t N, int64_t e_cap, int unit_weights, void* stream);
 
 /* ---------------------------------------------------------------- SpMM plan (once per graph)
  * Expands rowptr into a per-edge row-id stream and lists the empty rows, so the SpMM kernels

@@ -147,16 +147,28 @@ __global__ __launch_bounds__(kBlock) void row_weight_sum_kernel(const int64_t* _
   }
 }
 
-__global__ __launch_bounds__(kBlock) void gcn_scale_kernel(const int64_t* __restrict__ rowptr,
-                                                           const int32_t* __restrict__ col, float* __restrict__ val,
-                                                           const float* __restrict__ dinv, int64_t N) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
-  for (int64_t r = wave; r < N; r += nwaves) {
-    const int64_t b = rowptr[r], e = rowptr[r + 1];
-    const float dr = dinv[r];
-    for (int64_t k = b + lane; k < e; k += 64) val[k] = (dinv[col[k]] * val[k]) * dr;
+// unweighted graphs: deg[j] is just the row length (every stored weight is 1)
+__global__ __launch_bounds__(kBlock) void row_len_dinv_kernel(const int64_t* __restrict__ rowptr, int64_t N,
+                                                              float* __restrict__ dinv) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; r < N; r += stride) {
+    const float deg = static_cast<float>(rowptr[r + 1] - rowptr[r]);
+    float di = 1.0f / sqrtf(deg);
+    if (isinf(di)) di = 0.f;
+    dinv[r] = di;
+  }
+}
+
+// edge-parallel: val[k] = dinv[col[k]] * w_k * dinv[row(k)], row ids from the SpMM plan
+__global__ __launch_bounds__(kBlock) void gcn_scale_kernel(const int64_t* __restrict__ rowptr, int64_t N,
+                                                           const int32_t* __restrict__ col,
+                                                           const int32_t* __restrict__ rowid, float* __restrict__ val,
+                                                           const float* __restrict__ dinv, int unit) {
+  const int64_t E = rowptr[N];
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; k < E; k += stride) {
+    const float w = unit ? 1.f : val[k];
+    val[k] = (dinv[col[k]] * w) * dinv[rowid[k]];
   }
 }
 
@@ -225,14 +237,19 @@ LPG_EXPORT int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const floa
   return check_launch("coo_to_csr");
 }
 
-LPG_EXPORT int lpg_gcn_norm_csr(const int64_t* rowptr, const int32_t* col, float* val, float* dinv, int64_t N,
-                                void* stream) {
-  LPG_REQUIRE(N >= 0 && rowptr && val && dinv && col, "gcn_norm_csr: null pointer");
+LPG_EXPORT int lpg_gcn_norm_csr(const void* plan, const int64_t* rowptr, const int32_t* col, float* val, float* dinv,
+                                int64_t N, int64_t e_cap, int unit_weights, void* stream) {
+  LPG_REQUIRE(N >= 0 && e_cap >= 0 && plan && rowptr && val && dinv && (e_cap == 0 || col), "gcn_norm_csr: bad argument");
   if (N == 0) return LPG_OK;
   hipStream_t st = as_stream(stream);
-  const int grid = grid_for(N * 64);
-  hipLaunchKernelGGL(row_weight_sum_kernel, dim3(grid), dim3(kBlock), 0, st, rowptr, val, N, dinv);
-  hipLaunchKernelGGL(gcn_scale_kernel, dim3(grid), dim3(kBlock), 0, st, rowptr, col, val, dinv, N);
+  const int32_t* rowid = reinterpret_cast<const int32_t*>(static_cast<const char*>(plan) + 256);
+  if (unit_weights)
+    hipLaunchKernelGGL(row_len_dinv_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st, rowptr, N, dinv);
+  else
+    hipLaunchKernelGGL(row_weight_sum_kernel, dim3(grid_for(N * 64)), dim3(kBlock), 0, st, rowptr, val, N, dinv);
+  if (e_cap > 0)
+    hipLaunchKernelGGL(gcn_scale_kernel, dim3(grid_for(e_cap)), dim3(kBlock), 0, st, rowptr, N, col, rowid, val, dinv,
+                       unit_weights);
   return check_launch("gcn_norm_csr");
 }
 

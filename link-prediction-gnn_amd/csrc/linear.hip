@@ -1,11 +1,19 @@
-// Dense feature linear (K5):  Y[n,m] = X[n,k] @ W^T (+ bias)   on the fp32-input matrix cores.
+// Dense feature linear (K5):  Y[n,m] = act(X[n,k] @ W^T + bias)   on the fp32-input matrix cores.
 // Reference: GCNConv.lin (no bias, weight [out,in]) inside TwoWL/model/model.py:37 [3P PyG];
-// SEAL's tf.matmul(X, W) with W [in,out] (SEAL/model/gnn.py:46,50,54,58) -> w_is_km.
+// SEAL's tf.matmul(X, W) with W [in,out] (SEAL/model/gnn.py:46,50,54,58) -> w_is_km; SEAL's dense
+// layers relu(xW+b) (gnn.py:127,135).
 //
 // v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (bitwise a k-ordered fmaf chain),
-// which keeps the 1e-5 parity bar without any reduced-precision path.  A wave owns a 32x32
-// output tile; X and W tiles are staged through LDS with coalesced global reads and a +1 padded
-// row so the per-lane fragment reads (row = lane&31, k = 2*step + lane>>5) are conflict-free.
+// which keeps the 1e-5 parity bar without any reduced-precision path.
+//
+// Two shapes of workgroup:
+//  * ROWS (big n): a wave owns 32 rows and ALL of up to NT*32 output columns (NT accumulator tiles),
+//    so X is read from HBM exactly once; per 64-deep K step the workgroup stages its four 32-row X
+//    slices (16-byte loads) and the [NT*32, 64] W slice in LDS (+1 padded rows: conflict-free
+//    ds_read_b32 fragments).  At GNN sizes (k, m <= 256) the op is HBM-bound on X and Y.
+//  * SPLITK (small n, k > 64): the 4 waves share one 32-row tile and take every 4th K slice, partial
+//    tiles folded through LDS in wave order: 4x the workgroups and a quarter of the dependent
+//    staging steps -- the reference's own sizes ([620,256]x[256,32]) are latency bound.
 #include "lpg_common.hpp"
 
 namespace {
@@ -16,128 +24,196 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int KT = 64;       // k values staged per step
 constexpr int LDP = KT + 1;  // padded LDS row
 
-// SPLITK = false: the 4 waves of a workgroup own 4 different 32-row tiles and each walks all of K
-//                 (k <= 64: one staging step, nothing to split).
-// SPLITK = true : the 4 waves share ONE 32-row tile and take every 4th K-slice; the partial
-//                 accumulators are folded through LDS in wave order (fixed order => reproducible).
-//                 4x the workgroups and a quarter of the dependent staging steps per wave: at the
-//                 reference's sizes ([620,256]x[256,32]) the op is latency bound, not flop bound.
-template <bool SPLITK>
-__global__ __launch_bounds__(kBlock) void linear_mfma_f32_kernel(const float* __restrict__ x, int64_t ldx,
-                                                                 const float* __restrict__ w, int w_is_km,
-                                                                 const float* __restrict__ bias, int act,
-                                                                 float* __restrict__ y, int64_t ldy, int64_t n,
-                                                                 int64_t k, int64_t m) {
-  __shared__ float Xs[4][32][LDP];
-  __shared__ float Ws[SPLITK ? 4 : 1][32][LDP];
+__device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ bias, int act,
+                                           float* __restrict__ y, int64_t ldy, int64_t n, int64_t m, int64_t row0,
+                                           int64_t col, int lane) {
+  // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if (col >= m) return;
+  const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < n) y[row * ldy + col] = apply_act(acc[r] + b, act);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kBlock, 2) void linear_rows_f32_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                    const float* __restrict__ w, int w_is_km,
+                                                                    const float* __restrict__ bias, int act,
+                                                                    float* __restrict__ y, int64_t ldy, int64_t n,
+                                                                    int64_t k, int64_t m, int vec_ok, int wvec_ok) {
+  extern __shared__ float smem[];
+  float(*Xs)[32][LDP] = reinterpret_cast<float(*)[32][LDP]>(smem);                       // [4][32][LDP]
+  float(*Ws)[LDP] = reinterpret_cast<float(*)[LDP]>(smem + 4 * 32 * LDP);                // [NT*32][LDP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t row0 = SPLITK ? static_cast<int64_t>(blockIdx.x) * 32 : static_cast<int64_t>(blockIdx.x) * 128 + wave * 32;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * 128 + wave * 32;
+  const int64_t j0 = static_cast<int64_t>(blockIdx.y) * (NT * 32);
+  const int fr = lane & 31, fk = lane >> 5;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  for (int64_t k0 = 0; k0 < k; k0 += KT) {
+    // ---- stage X (own 32 rows) : loads first, selects + LDS writes after a compiler barrier
+    if (vec_ok) {
+      float4 xr[8];               // 32 rows x 64 k = 512 float4, 8 per lane: piece = it*64+lane -> (row, seg)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int piece = it * 64 + lane, r = piece >> 4, seg = piece & 15;
+        const int64_t row = row0 + r, kk = k0 + seg * 4;
+        const bool ok = row < n && kk < k;            // k % 4 == 0: a piece is all-in or all-out
+        xr[it] = *reinterpret_cast<const float4*>(x + (ok ? row * ldx + kk : 0));
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int piece = it * 64 + lane, r = piece >> 4, seg = piece & 15;
+        const bool ok = row0 + r < n && k0 + seg * 4 < k;
+        float* dst = &Xs[wave][r][seg * 4];
+        dst[0] = ok ? xr[it].x : 0.f; dst[1] = ok ? xr[it].y : 0.f;
+        dst[2] = ok ? xr[it].z : 0.f; dst[3] = ok ? xr[it].w : 0.f;
+      }
+    } else {
+      float xr[32];
+#pragma unroll
+      for (int it = 0; it < 32; ++it) {
+        const int64_t r = row0 + it, kk = k0 + lane;
+        xr[it] = x[(r < n ? r : n - 1) * ldx + (kk < k ? kk : k - 1)];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 32; ++it) Xs[wave][it][lane] = (row0 + it < n && k0 + lane < k) ? xr[it] : 0.f;
+    }
+    // ---- stage W slice [NT*32 columns][KT] = NT*512 float4 pieces, NT*2 per thread (16-byte loads
+    // along the contiguous dimension of W: k for [m,k], m for [k,m]); scalar fallback otherwise
+    if (wvec_ok) {
+      float4 wr[NT * 2];
+#pragma unroll
+      for (int it = 0; it < NT * 2; ++it) {
+        const int piece = it * kBlock + tid;
+        int j, kk;
+        if (w_is_km) { kk = piece / (NT * 8); j = (piece % (NT * 8)) * 4; }    // 4 consecutive output columns
+        else { j = piece >> 4; kk = (piece & 15) * 4; }                        // 4 consecutive k
+        const bool ok = k0 + kk < k && j0 + j < m;                             // k % 4 == 0 resp. m % 4 == 0
+        const int64_t off = w_is_km ? (k0 + kk) * m + j0 + j : (j0 + j) * k + k0 + kk;
+        wr[it] = *reinterpret_cast<const float4*>(w + (ok ? off : 0));
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < NT * 2; ++it) {
+        const int piece = it * kBlock + tid;
+        int j, kk;
+        if (w_is_km) { kk = piece / (NT * 8); j = (piece % (NT * 8)) * 4; }
+        else { j = piece >> 4; kk = (piece & 15) * 4; }
+        const bool ok = k0 + kk < k && j0 + j < m;
+        const float4 v = ok ? wr[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w_is_km) { Ws[j][kk] = v.x; Ws[j + 1][kk] = v.y; Ws[j + 2][kk] = v.z; Ws[j + 3][kk] = v.w; }
+        else { Ws[j][kk] = v.x; Ws[j][kk + 1] = v.y; Ws[j][kk + 2] = v.z; Ws[j][kk + 3] = v.w; }
+      }
+    } else {
+#pragma unroll 4
+      for (int it = 0; it < NT * 8; ++it) {
+        const int idx = it * kBlock + tid;
+        const int kk = w_is_km ? idx / (NT * 32) : idx & 63, j = w_is_km ? idx % (NT * 32) : idx >> 6;
+        const bool ok = k0 + kk < k && j0 + j < m;
+        const int64_t off = w_is_km ? (k0 + kk) * m + j0 + j : (j0 + j) * k + k0 + kk;
+        Ws[j][kk] = ok ? w[off] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < KT; kk += 2) {
+      const float a = Xs[wave][fr][kk + fk];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Ws[t * 32 + fr][kk + fk], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) store_tile(acc[t], bias, act, y, ldy, n, m, row0, j0 + t * 32 + (lane & 31), lane);
+}
+
+__global__ __launch_bounds__(kBlock) void linear_splitk_f32_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                   const float* __restrict__ w, int w_is_km,
+                                                                   const float* __restrict__ bias, int act,
+                                                                   float* __restrict__ y, int64_t ldy, int64_t n,
+                                                                   int64_t k, int64_t m) {
+  __shared__ float Xs[4][32][LDP];
+  __shared__ float Ws[4][32][LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * 32;
   const int64_t j0 = static_cast<int64_t>(blockIdx.y) * 32;
+  const int fr = lane & 31, fk = lane >> 5;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int fr = lane & 31, fk = lane >> 5;
+  for (int64_t k0 = static_cast<int64_t>(wave) * KT; k0 < k; k0 += 4 * KT) {
+    // every wave stages its own X slice and its own W slice: no workgroup barrier in the loop.
+    // Two phases with a compiler barrier between them: all 64 loads are issued from clamped
+    // addresses first, the selects and LDS writes follow (written as `cond ? load : 0`, hipcc
+    // branches around every load and waits vmcnt(0) 64 times -- 64 dependent round trips).
+    float xr[32], wr[32];
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int64_t r = row0 + it, kk = k0 + lane;
+      xr[it] = x[(r < n ? r : n - 1) * ldx + (kk < k ? kk : k - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      if (w_is_km) {            // W[k][m]: lanes 0-31 walk m for k-row 2*it + fk
+        const bool ok = k0 + 2 * it + fk < k && j0 + fr < m;
+        wr[it] = w[(ok ? k0 + 2 * it + fk : 0) * m + (ok ? j0 + fr : 0)];
+      } else {                  // W[m][k]: lanes walk k for output column `it`
+        const bool ok = k0 + lane < k && j0 + it < m;
+        wr[it] = w[(ok ? j0 + it : 0) * k + (ok ? k0 + lane : 0)];
+      }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int64_t r = row0 + it, kk = k0 + lane;
+      Xs[wave][it][lane] = (r < n && kk < k) ? xr[it] : 0.f;
+      if (w_is_km)
+        Ws[wave][fr][2 * it + fk] = (k0 + 2 * it + fk < k && j0 + fr < m) ? wr[it] : 0.f;
+      else
+        Ws[wave][it][lane] = (k0 + lane < k && j0 + it < m) ? wr[it] : 0.f;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes are done (wave-private slices)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+    for (int kk = 0; kk < KT; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[wave][fr][kk + fk], Ws[wave][fr][kk + fk], acc, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+  }
+  // fold the 4 partial tiles in wave order through LDS (reuse Xs as [4][16][64] floats)
+  float* red = &Xs[0][0][0];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    acc[r] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) +
+             red[(3 * 16 + r) * 64 + lane];
+  store_tile(acc, bias, act, y, ldy, n, m, row0, j0 + (lane & 31), lane);
+}
 
-  if constexpr (SPLITK) {
-    for (int64_t k0 = static_cast<int64_t>(wave) * KT; k0 < k; k0 += 4 * KT) {
-      // every wave stages its own X slice and its own W slice: no workgroup barrier in the loop.
-      // Two phases with a compiler barrier between them: all 64 loads are issued from clamped
-      // addresses first, the selects and LDS writes follow (written as `cond ? load : 0`, hipcc
-      // branches around every load and waits vmcnt(0) 64 times -- 64 dependent round trips).
-      float xr[32], wr[32];
-#pragma unroll
-      for (int it = 0; it < 32; ++it) {
-        const int64_t r = row0 + it, kk = k0 + lane;
-        xr[it] = x[(r < n ? r : n - 1) * ldx + (kk < k ? kk : k - 1)];
-      }
-#pragma unroll
-      for (int it = 0; it < 32; ++it) {
-        if (w_is_km) {            // W[k][m]: lanes 0-31 walk m for k-row 2*it + fk
-          const bool ok = k0 + 2 * it + fk < k && j0 + fr < m;
-          wr[it] = w[(ok ? k0 + 2 * it + fk : 0) * m + (ok ? j0 + fr : 0)];
-        } else {                  // W[m][k]: lanes walk k for output column `it`
-          const bool ok = k0 + lane < k && j0 + it < m;
-          wr[it] = w[(ok ? j0 + it : 0) * k + (ok ? k0 + lane : 0)];
-        }
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int it = 0; it < 32; ++it) {
-        const int64_t r = row0 + it, kk = k0 + lane;
-        Xs[wave][it][lane] = (r < n && kk < k) ? xr[it] : 0.f;
-        if (w_is_km)
-          Ws[wave][fr][2 * it + fk] = (k0 + 2 * it + fk < k && j0 + fr < m) ? wr[it] : 0.f;
-        else
-          Ws[wave][it][lane] = (k0 + lane < k && j0 + it < m) ? wr[it] : 0.f;
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes are done (wave-private slices)
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll 8
-      for (int kk = 0; kk < KT; kk += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[wave][fr][kk + fk], Ws[wave][fr][kk + fk], acc, 0, 0, 0);
-      __builtin_amdgcn_wave_barrier();
-    }
-    // fold the 4 partial tiles in wave order through LDS (reuse Xs as [4][16][64] floats)
-    float* red = &Xs[0][0][0];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        acc[r] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) +
-                 red[(3 * 16 + r) * 64 + lane];
-    } else {
-      return;
-    }
-  } else {
-    for (int64_t k0 = 0; k0 < k; k0 += KT) {
-      // X tile: each wave stages its own 32 rows (one 256-byte row segment per instruction);
-      // W tile (32 output columns x KT) is shared by the 4 waves.  Loads first, selects after.
-      float xr[32], wr[(32 * KT) / kBlock];
-#pragma unroll
-      for (int it = 0; it < 32; ++it) {
-        const int64_t r = row0 + it, kk = k0 + lane;
-        xr[it] = x[(r < n ? r : n - 1) * ldx + (kk < k ? kk : k - 1)];
-      }
-#pragma unroll
-      for (int it = 0; it < (32 * KT) / kBlock; ++it) {
-        const int idx = it * kBlock + tid;
-        const int kk = w_is_km ? idx >> 5 : idx & 63, j = w_is_km ? idx & 31 : idx >> 6;
-        const bool ok = k0 + kk < k && j0 + j < m;
-        const int64_t off = w_is_km ? (k0 + kk) * m + j0 + j : (j0 + j) * k + k0 + kk;
-        wr[it] = w[ok ? off : 0];
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int it = 0; it < 32; ++it) {
-        const int64_t r = row0 + it, kk = k0 + lane;
-        Xs[wave][it][lane] = (r < n && kk < k) ? xr[it] : 0.f;
-      }
-#pragma unroll
-      for (int it = 0; it < (32 * KT) / kBlock; ++it) {
-        const int idx = it * kBlock + tid;
-        const int kk = w_is_km ? idx >> 5 : idx & 63, j = w_is_km ? idx & 31 : idx >> 6;
-        Ws[0][j][kk] = (k0 + kk < k && j0 + j < m) ? wr[it] : 0.f;
-      }
-      __syncthreads();
-#pragma unroll 8
-      for (int kk = 0; kk < KT; kk += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[wave][fr][kk + fk], Ws[0][fr][kk + fk], acc, 0, 0, 0);
-      __syncthreads();
-    }
-  }
-  // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int64_t col = j0 + (lane & 31);
-  if (col < m) {
-    const float b = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < n) y[row * ldy + col] = apply_act(acc[r] + b, act);
-    }
-  }
+template <int NT>
+int launch_rows(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, int act, float* y,
+                int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st) {
+  const int64_t gx = ceil_div(n, 128), gy = ceil_div(m, NT * 32);
+  LPG_REQUIRE(gx < (int64_t(1) << 31) && gy < 65536, "linear: grid too large");
+  const int vec_ok = k % 4 == 0 && ldx % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+  const int wvec_ok = reinterpret_cast<uintptr_t>(w) % 16 == 0 && (w_is_km ? m % 4 == 0 : k % 4 == 0);
+  const size_t lds = static_cast<size_t>(4 * 32 + NT * 32) * LDP * sizeof(float);
+  hipLaunchKernelGGL(linear_rows_f32_kernel<NT>, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)),
+                     dim3(kBlock), lds, st, x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, vec_ok, wvec_ok);
+  return LPG_OK;
 }
 }  // namespace
 
@@ -148,17 +224,20 @@ LPG_EXPORT int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w
               (long long)n, (long long)k, (long long)m);
   if (n == 0) return LPG_OK;
   LPG_REQUIRE(x && w && y, "linear: null pointer");
+  hipStream_t st = as_stream(stream);
   // split K across the 4 waves when there is more than one K-slice and the problem is small enough
-  // to be latency bound (few row tiles); big problems keep 128 rows per workgroup.
-  const bool splitk = k > KT && n <= (int64_t(1) << 16);
-  const int64_t gx = ceil_div(n, splitk ? 32 : 128), gy = ceil_div(m, 32);
-  LPG_REQUIRE(gx < (int64_t(1) << 31) && gy < 65536, "linear: grid too large");
-  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy));
-  if (splitk)
-    hipLaunchKernelGGL(linear_mfma_f32_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, w, w_is_km, bias,
-                       act, y, ldy, n, k, m);
-  else
-    hipLaunchKernelGGL(linear_mfma_f32_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, w, w_is_km, bias,
-                       act, y, ldy, n, k, m);
+  // to be latency bound (few row tiles); big problems read X once with all columns per wave.
+  if (k > KT && n <= (int64_t(1) << 16)) {
+    const int64_t gx = ceil_div(n, 32), gy = ceil_div(m, 32);
+    LPG_REQUIRE(gy < 65536, "linear: grid too large");
+    hipLaunchKernelGGL(linear_splitk_f32_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)),
+                       dim3(kBlock), 0, st, x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m);
+    return check_launch("linear");
+  }
+  int rc;
+  if (m <= 32) rc = launch_rows<1>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+  else if (m <= 64) rc = launch_rows<2>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+  else rc = launch_rows<4>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);      // wider m: column tiles of 128
+  if (rc != LPG_OK) return rc;
   return check_launch("linear");
 }

@@ -12,36 +12,75 @@
 namespace {
 using namespace lpg;
 
-constexpr int kMaxPartBlocks = 512;
+constexpr int kMaxPartBlocks = 2048;
 
+// Per-block column sums of x and x^2 in fp64.  A thread owns VEC consecutive columns (one 16-byte
+// load per row when VEC = 4) and walks its block's rows with a stride of R = 256 / (threads per row),
+// four rows per step so four independent loads are in flight; the R partial sums per column are
+// folded through LDS in a fixed order.
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void gn_partial_kernel(const float* __restrict__ x, int64_t n, int64_t d,
-                                                            int64_t rows_per_block, int dp_cols,
+                                                            int64_t rows_per_block, int tpr,
                                                             double* __restrict__ part) {
-  __shared__ double sh[2][kBlock];
-  const int R = kBlock / dp_cols;  // rows handled per sweep
-  const int cl = threadIdx.x % dp_cols, rl = threadIdx.x / dp_cols;
+  __shared__ double sh[2][kBlock][VEC];
+  const int R = kBlock / tpr;        // rows handled per sweep
+  const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   const int64_t rb = static_cast<int64_t>(blockIdx.x) * rows_per_block;
   int64_t re = rb + rows_per_block;
   if (re > n) re = n;
-  for (int64_t cb = 0; cb < d; cb += dp_cols) {
-    const int64_t c = cb + cl;
-    double s = 0.0, s2 = 0.0;
-    if (c < d)
-      for (int64_t r = rb + rl; r < re; r += R) {
-        const double v = static_cast<double>(x[r * d + c]);
-        s += v;
-        s2 += v * v;
+  for (int64_t cb = 0; cb < d; cb += static_cast<int64_t>(tpr) * VEC) {
+    const int64_t c = cb + static_cast<int64_t>(cl) * VEC;
+    double s[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] = s2[i] = 0.0;
+    if (c < d) {
+      int64_t r = rb + rl;
+      for (; r + 3 * R < re; r += 4 * R) {
+        float v[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if constexpr (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(x + (r + u * R) * d + c);
+            v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+          } else {
+            v[u][0] = x[(r + u * R) * d + c];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const double t = static_cast<double>(v[u][i]);
+            s[i] += t;
+            s2[i] += t * t;
+          }
       }
-    sh[0][threadIdx.x] = s;
-    sh[1][threadIdx.x] = s2;
+      for (; r < re; r += R)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const double t = static_cast<double>(x[r * d + c + i]);
+          s[i] += t;
+          s2[i] += t * t;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      sh[0][threadIdx.x][i] = s[i];
+      sh[1][threadIdx.x][i] = s2[i];
+    }
     __syncthreads();
     if (rl == 0 && c < d) {
-      for (int q = 1; q < R; ++q) {  // fixed order
-        s += sh[0][q * dp_cols + cl];
-        s2 += sh[1][q * dp_cols + cl];
+      for (int q = 1; q < R; ++q)    // fixed order
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          s[i] += sh[0][q * tpr + cl][i];
+          s2[i] += sh[1][q * tpr + cl][i];
+        }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        part[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * d + c + i] = s[i];
+        part[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * d + c + i] = s2[i];
       }
-      part[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * d + c] = s;
-      part[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * d + c] = s2;
     }
     __syncthreads();
   }
@@ -146,9 +185,14 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
   float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + static_cast<int64_t>(kMaxPartBlocks) * 2 * d * 8);
   int64_t rpb;
   const int nb = part_blocks(n, &rpb);
-  int dp = 1;
-  while (dp < d && dp < kBlock) dp <<= 1;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nb), dim3(kBlock), 0, st, x, n, d, rpb, dp, part);
+  const bool wide_in = d % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+  const int64_t cols = wide_in ? d / 4 : d;          // threads needed per row
+  int tpr = 1;
+  while (tpr < cols && tpr < kBlock) tpr <<= 1;
+  if (wide_in)
+    hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nb), dim3(kBlock), 0, st, x, n, d, rpb, tpr, part);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nb), dim3(kBlock), 0, st, x, n, d, rpb, tpr, part);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(grid_for(d * 64)), dim3(kBlock), 0, st, part, nb, n, d, weight, bias,
                      mean_scale, eps, stats);
   const bool wide = d % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&

@@ -162,11 +162,12 @@ class CSRGraph:
     def gcn_normalize_(self):
         """val <- D^-1/2 val D^-1/2 with D = destination weight sums (PyG gcn_norm)."""
         lib = _lib.load()
-        if self.val is None:
-            self.val = torch.ones(max(self.e_cap, 1), dtype=torch.float32, device=self.device)
+        unit = self.val is None
+        if unit:
+            self.val = torch.empty(max(self.e_cap, 1), dtype=torch.float32, device=self.device)
         self.dinv = torch.empty(max(self.n_rows, 1), dtype=torch.float32, device=self.device)
-        _lib.check(lib.lpg_gcn_norm_csr(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), _ptr(self.dinv),
-                                        self.n_rows, _stream()), "gcn_norm_csr")
+        _lib.check(lib.lpg_gcn_norm_csr(_ptr(self._plan), _ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
+                                        _ptr(self.dinv), self.n_rows, self.e_cap, int(unit), _stream()), "gcn_norm_csr")
         return self
 
     def nnz(self):

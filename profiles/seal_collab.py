@@ -42,9 +42,17 @@ hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, device=dev) * 0.1, "conv1d_kerne
       "weight_2": torch.randn(128, 2, device=dev), "bias_2": torch.zeros(2, device=dev)}
 
 
+BF16 = "--bf16" in sys.argv          # configs[2] says bf16: features, weights and activations stored in bf16
+gw16 = [w.bfloat16() for w in gw]
+
+
 def score():
     batch, T, g, d_inv, x = run()
-    z, key = seal.graph_conv_stack(g, d_inv, x, gw)
+    if BF16:
+        z, key = seal.graph_conv_stack(g, d_inv, x.bfloat16(), gw16)
+        z, key = z.float(), key.float()
+    else:
+        z, key = seal.graph_conv_stack(g, d_inv, x, gw)
     return seal.head(z, key, batch.node_off(), hw)[1], batch, g
 
 
@@ -61,7 +69,7 @@ for _ in range(it):
     run()
 torch.cuda.synchronize()
 dt_struct = (time.time() - t0) / it
-print(json.dumps({"workload": f"synthetic collab-shaped SEAL: |V|={N} undirected |E|={E}, {B} candidate pairs, d={D} fp32",
+print(json.dumps({"workload": f"synthetic collab-shaped SEAL: |V|={N} undirected |E|={E}, {B} candidate pairs, d={D} " + ("bf16 storage" if BF16 else "fp32"),
                   "tags_size": T, "total_vertices": int(batch.n.sum()), "block_csr_nnz": g.nnz(),
                   "capped_pairs": int(batch.capped.sum()), "ms_total": dt * 1e3, "ms_structure_and_inputs": dt_struct * 1e3,
                   "scored_edges_per_s": B / dt}))
