@@ -1,6 +1,7 @@
 """CPU oracle -- TEST INFRASTRUCTURE ONLY.
 
-A CPU restatement (numpy; plain C for the fp32 same-order SpMM loop) of the reference's
+A CPU restatement (numpy; plain C -- spmm_ref.c, built by oracle/Makefile -- for the fp32
+same-order SpMM loop) of the reference's
 aggregation hot path, each function citing the reference file:line it follows.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import

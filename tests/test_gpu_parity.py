@@ -769,3 +769,23 @@ def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
     z16, k16 = seal.graph_conv_stack(g, d_inv, x.bfloat16(), [w1.bfloat16()] + [w.bfloat16() for w in gw[1:]])
     assert z16.dtype == torch.bfloat16
     assert float((z16.float() - z32).abs().max()) < 0.03 and float((k16.float() - k32).abs().max()) < 0.03
+
+
+@pytest.mark.parametrize("d,weighted", [(128, False), (128, True), (32, True), (64, False), (3, True), (256, False)])
+def test_spmm_bit_exact_vs_same_order_c_loop(dev, d, weighted):
+    """the atomic-free SpMM equals a plain fp32 CPU loop that adds in the same
+    order (oracle/spmm_ref.c: CSR order inside a chunk, chunk pieces left to right) BIT FOR BIT."""
+    import lpgnn_amd
+    from oracle import aggregation as agg, spmm_c
+    rng = np.random.default_rng(40 + d)
+    n_rows, n_cols, E = 3000, 2500, 90000
+    ei = rand_graph(rng, n_rows, n_cols, E, hub=0.25, empty_frac=0.1)
+    w = rng.standard_normal(ei.shape[1]).astype(np.float32) if weighted else None
+    x = rng.standard_normal((n_cols, d)).astype(np.float32)
+    g = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n_rows, n_cols,
+                                           None if w is None else torch.from_numpy(w).to(dev))
+    y = _np(g.spmm(torch.from_numpy(x).to(dev)))
+    chunk = lpgnn_amd.load_library().lpg_spmm_chunk_edges(g.e_cap)
+    rowptr, col, val, _ = agg.coo_to_csr(ei[1], ei[0], n_rows, w)
+    want = spmm_c.spmm_f32_chunked(rowptr, col, val, x, chunk)
+    assert np.array_equal(y, want), float(np.abs(y - want).max())

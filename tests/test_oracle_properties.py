@@ -90,3 +90,22 @@ def test_drnl_invariants(n, seed):
     for i in range(2, n):                                     # direct common neighbour of both targets -> 2
         if a[0, i] and a[1, i]:
             assert tags[i] == 2
+
+
+def test_c_restatement_matches_numpy_oracle():
+    """oracle/spmm_ref.c (fp32, kernel association order) vs the fp64 numpy restatement."""
+    from oracle import spmm_c
+    rng = np.random.default_rng(5)
+    n, e, d = 200, 5000, 12
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    dst[:1500] = 7                                        # one row spanning many chunks
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    for w in (None, rng.standard_normal(e).astype(np.float32)):
+        rp, col, val, _ = agg.coo_to_csr(dst, src, n, w)
+        want = agg.csr_spmm(rp, col, val, x)
+        mag = agg.spmm_abs_rowsum(rp, col, val, x)
+        for chunk in (16, 64, 512):
+            got = spmm_c.spmm_f32_chunked(rp, col, val, x, chunk)
+            assert np.all(np.abs(got - want) <= 1e-5 * mag + 1e-30)
+        got = spmm_c.scatter_add_f32(src, dst, w, x, n)
+        assert np.all(np.abs(got - want) <= 1e-5 * mag + 1e-30)
