@@ -37,12 +37,17 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
   }
 }
 
-template <int NT>
+// FAST: every operand is 16-byte aligned (k % 4 == 0, W's contiguous dimension % 4 == 0, m % 4 == 0):
+//   * register prefetch: the global loads of K step s+1 are issued right after the barrier that
+//     publishes step s in LDS, so they fly during the MFMAs of step s;
+//   * the output tile goes back through LDS and is written as whole 16-byte pieces of a row.
+// !FAST: scalar staging with bounds selects (any alignment, any k / m).
+template <int NT, bool FAST>
 __global__ __launch_bounds__(kBlock, 2) void linear_rows_f32_kernel(const float* __restrict__ x, int64_t ldx,
                                                                     const float* __restrict__ w, int w_is_km,
                                                                     const float* __restrict__ bias, int act,
                                                                     float* __restrict__ y, int64_t ldy, int64_t n,
-                                                                    int64_t k, int64_t m, int vec_ok, int wvec_ok) {
+                                                                    int64_t k, int64_t m) {
   extern __shared__ float smem[];
   float(*Xs)[32][LDP] = reinterpret_cast<float(*)[32][LDP]>(smem);                       // [4][32][LDP]
   float(*Ws)[LDP] = reinterpret_cast<float(*)[LDP]>(smem + 4 * 32 * LDP);                // [NT*32][LDP]
@@ -56,18 +61,38 @@ __global__ __launch_bounds__(kBlock, 2) void linear_rows_f32_kernel(const float*
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  for (int64_t k0 = 0; k0 < k; k0 += KT) {
-    // ---- stage X (own 32 rows) : loads first, selects + LDS writes after a compiler barrier
-    if (vec_ok) {
-      float4 xr[8];               // 32 rows x 64 k = 512 float4, 8 per lane: piece = it*64+lane -> (row, seg)
+  auto mfma_step = [&]() {
+#pragma unroll 4
+    for (int kk = 0; kk < KT; kk += 2) {
+      const float a = Xs[wave][fr][kk + fk];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Ws[t * 32 + fr][kk + fk], acc[t], 0, 0, 0);
+    }
+  };
+
+  if constexpr (FAST) {
+    float4 xr[8], wr[NT * 2];   // X: 32 rows x 64 k = 512 pieces, 8 per lane; W: NT*512 pieces, NT*2 per thread
+    auto load_stage = [&](int64_t k0) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int piece = it * 64 + lane, r = piece >> 4, seg = piece & 15;
         const int64_t row = row0 + r, kk = k0 + seg * 4;
-        const bool ok = row < n && kk < k;            // k % 4 == 0: a piece is all-in or all-out
+        const bool ok = row < n && kk < k;
         xr[it] = *reinterpret_cast<const float4*>(x + (ok ? row * ldx + kk : 0));
       }
-      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < NT * 2; ++it) {
+        const int piece = it * kBlock + tid;
+        int j, kk;
+        if (w_is_km) { kk = piece / (NT * 8); j = (piece % (NT * 8)) * 4; }    // 4 consecutive output columns
+        else { j = piece >> 4; kk = (piece & 15) * 4; }                        // 4 consecutive k
+        const bool ok = k0 + kk < k && j0 + j < m;
+        const int64_t off = w_is_km ? (k0 + kk) * m + j0 + j : (j0 + j) * k + k0 + kk;
+        wr[it] = *reinterpret_cast<const float4*>(w + (ok ? off : 0));
+      }
+    };
+    auto store_stage = [&](int64_t k0) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int piece = it * 64 + lane, r = piece >> 4, seg = piece & 15;
@@ -76,32 +101,6 @@ __global__ __launch_bounds__(kBlock, 2) void linear_rows_f32_kernel(const float*
         dst[0] = ok ? xr[it].x : 0.f; dst[1] = ok ? xr[it].y : 0.f;
         dst[2] = ok ? xr[it].z : 0.f; dst[3] = ok ? xr[it].w : 0.f;
       }
-    } else {
-      float xr[32];
-#pragma unroll
-      for (int it = 0; it < 32; ++it) {
-        const int64_t r = row0 + it, kk = k0 + lane;
-        xr[it] = x[(r < n ? r : n - 1) * ldx + (kk < k ? kk : k - 1)];
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int it = 0; it < 32; ++it) Xs[wave][it][lane] = (row0 + it < n && k0 + lane < k) ? xr[it] : 0.f;
-    }
-    // ---- stage W slice [NT*32 columns][KT] = NT*512 float4 pieces, NT*2 per thread (16-byte loads
-    // along the contiguous dimension of W: k for [m,k], m for [k,m]); scalar fallback otherwise
-    if (wvec_ok) {
-      float4 wr[NT * 2];
-#pragma unroll
-      for (int it = 0; it < NT * 2; ++it) {
-        const int piece = it * kBlock + tid;
-        int j, kk;
-        if (w_is_km) { kk = piece / (NT * 8); j = (piece % (NT * 8)) * 4; }    // 4 consecutive output columns
-        else { j = piece >> 4; kk = (piece & 15) * 4; }                        // 4 consecutive k
-        const bool ok = k0 + kk < k && j0 + j < m;                             // k % 4 == 0 resp. m % 4 == 0
-        const int64_t off = w_is_km ? (k0 + kk) * m + j0 + j : (j0 + j) * k + k0 + kk;
-        wr[it] = *reinterpret_cast<const float4*>(w + (ok ? off : 0));
-      }
-      asm volatile("" ::: "memory");
 #pragma unroll
       for (int it = 0; it < NT * 2; ++it) {
         const int piece = it * kBlock + tid;
@@ -113,7 +112,50 @@ __global__ __launch_bounds__(kBlock, 2) void linear_rows_f32_kernel(const float*
         if (w_is_km) { Ws[j][kk] = v.x; Ws[j + 1][kk] = v.y; Ws[j + 2][kk] = v.z; Ws[j + 3][kk] = v.w; }
         else { Ws[j][kk] = v.x; Ws[j][kk + 1] = v.y; Ws[j][kk + 2] = v.z; Ws[j][kk + 3] = v.w; }
       }
-    } else {
+    };
+    load_stage(0);
+    for (int64_t k0 = 0; k0 < k; k0 += KT) {
+      asm volatile("" ::: "memory");
+      store_stage(k0);
+      __syncthreads();
+      if (k0 + KT < k) load_stage(k0 + KT);          // in flight while this step's MFMAs run
+      mfma_step();
+      __syncthreads();
+    }
+    // ---- epilogue through LDS: the wave's [32][NT*32] tile, then 16-byte row pieces
+    constexpr int TW = NT * 32 + (NT == 4 ? 0 : 4);  // tile row (floats); 4 * 32 * TW * 4 B fits the staging area
+    static_assert(4 * 32 * TW <= (4 * 32 + NT * 32) * LDP, "output tiles must fit in the staging LDS");
+    float* tile = smem + wave * 32 * TW;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c = t * 32 + (lane & 31);
+      const float b = (bias && j0 + c < m) ? bias[j0 + c] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        tile[row * TW + c] = apply_act(acc[t][r] + b, act);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0); the tile is wave-private
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NT * 4; ++it) {            // 32 rows x NT*8 pieces = NT*256 pieces, NT*4 per lane
+      const int piece = it * 64 + lane, r = piece / (NT * 8), c = (piece % (NT * 8)) * 4;
+      const int64_t row = row0 + r, col = j0 + c;
+      if (row < n && col < m)                        // m % 4 == 0: a piece is all-in or all-out
+        *reinterpret_cast<float4*>(y + row * ldy + col) = *reinterpret_cast<const float4*>(&tile[r * TW + c]);
+    }
+  } else {
+    for (int64_t k0 = 0; k0 < k; k0 += KT) {
+      float xr[32];
+#pragma unroll
+      for (int it = 0; it < 32; ++it) {
+        const int64_t r = row0 + it, kk = k0 + lane;
+        xr[it] = x[(r < n ? r : n - 1) * ldx + (kk < k ? kk : k - 1)];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 32; ++it) Xs[wave][it][lane] = (row0 + it < n && k0 + lane < k) ? xr[it] : 0.f;
 #pragma unroll 4
       for (int it = 0; it < NT * 8; ++it) {
         const int idx = it * kBlock + tid;
@@ -122,19 +164,13 @@ __global__ __launch_bounds__(kBlock, 2) void linear_rows_f32_kernel(const float*
         const int64_t off = w_is_km ? (k0 + kk) * m + j0 + j : (j0 + j) * k + k0 + kk;
         Ws[j][kk] = ok ? w[off] : 0.f;
       }
+      __syncthreads();
+      mfma_step();
+      __syncthreads();
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int kk = 0; kk < KT; kk += 2) {
-      const float a = Xs[wave][fr][kk + fk];
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Ws[t * 32 + fr][kk + fk], acc[t], 0, 0, 0);
-    }
-    __syncthreads();
+    for (int t = 0; t < NT; ++t) store_tile(acc[t], bias, act, y, ldy, n, m, row0, j0 + t * 32 + (lane & 31), lane);
   }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) store_tile(acc[t], bias, act, y, ldy, n, m, row0, j0 + t * 32 + (lane & 31), lane);
 }
 
 __global__ __launch_bounds__(kBlock) void linear_splitk_f32_kernel(const float* __restrict__ x, int64_t ldx,
@@ -208,11 +244,17 @@ int launch_rows(const float* x, int64_t ldx, const float* w, int w_is_km, const 
                 int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st) {
   const int64_t gx = ceil_div(n, 128), gy = ceil_div(m, NT * 32);
   LPG_REQUIRE(gx < (int64_t(1) << 31) && gy < 65536, "linear: grid too large");
-  const int vec_ok = k % 4 == 0 && ldx % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
-  const int wvec_ok = reinterpret_cast<uintptr_t>(w) % 16 == 0 && (w_is_km ? m % 4 == 0 : k % 4 == 0);
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  const bool fast = k % 4 == 0 && ldx % 4 == 0 && m % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(w) && al16(y) &&
+                    (w_is_km ? true : k % 4 == 0);
   const size_t lds = static_cast<size_t>(4 * 32 + NT * 32) * LDP * sizeof(float);
-  hipLaunchKernelGGL(linear_rows_f32_kernel<NT>, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)),
-                     dim3(kBlock), lds, st, x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, vec_ok, wvec_ok);
+  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy));
+  if (fast)
+    hipLaunchKernelGGL((linear_rows_f32_kernel<NT, true>), grid, dim3(kBlock), lds, st, x, ldx, w, w_is_km, bias, act, y,
+                       ldy, n, k, m);
+  else
+    hipLaunchKernelGGL((linear_rows_f32_kernel<NT, false>), grid, dim3(kBlock), lds, st, x, ldx, w, w_is_km, bias, act,
+                       y, ldy, n, k, m);
   return LPG_OK;
 }
 }  // namespace
