@@ -98,7 +98,8 @@ int lpg_csr_plan_build(const int64_t* rowptr, const int32_t* col, int64_t N, int
  * torch_sparse.spmm / matmul(reduce="sum") and the propagate step of GCNConv
  * [TwoWL/model/model.py:73,77]; with row_scale = D^-1, act = tanh it is SEAL's
  * tanh(D^-1 (A~ (X W)))  [SEAL/model/gnn.py:47-48,51-52,55-56,59-60].
- * val == NULL: all ones.  row_scale / bias may be NULL.  ldx/ldy = row strides in elements.
+ * val == NULL: all ones.  row_scale / bias may be NULL.  ldx/ldy = row strides in elements;
+ * n_cols = rows of x (the bound the plan checked `col` against).
  * Atomic-free and bitwise reproducible: edges are cut into fixed chunks, rows that straddle
  * chunks are finished by a second kernel that adds the partials in chunk order.
  * bf16 variant: x, y are bfloat16 (uint16 bit patterns), accumulation in fp32.
@@ -107,12 +108,12 @@ int lpg_csr_plan_build(const int64_t* rowptr, const int32_t* col, int64_t N, int
 int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d);
 int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col,
                      const float* val, const float* x, int64_t ldx, float* y, int64_t ldy,
-                     int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
+                     int64_t N, int64_t n_cols, int64_t e_cap, int64_t d, const float* row_scale,
                      const float* bias, int act, int64_t n_empty_hint, void* workspace,
                      int64_t workspace_bytes, void* stream);
 int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* col,
                       const float* val, const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy,
-                      int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
+                      int64_t N, int64_t n_cols, int64_t e_cap, int64_t d, const float* row_scale,
                       const float* bias, int act, int64_t n_empty_hint, void* workspace,
                       int64_t workspace_bytes, void* stream);
 

@@ -58,9 +58,21 @@ __device__ __forceinline__ void flag_error(int32_t* err_flag, int32_t bit) {
   if (err_flag) atomicOr(err_flag, bit);
 }
 
+// tanh through one v_exp_f32: tanh(v) = 1 - 2 / (exp(2v) + 1).  libm's tanhf inlines ~60
+// instructions at every call site (the SpMM flushes rows at 8 unrolled sites); this form is ~6 and
+// accurate to ~2e-7 absolute on |tanh| <= 1 (parity bar 1e-5).  Saturates cleanly: exp -> inf gives 1,
+// exp -> 0 gives -1.
+__device__ __forceinline__ float fast_tanh(float v) {
+  const float v2 = v * v;
+  if (v2 < 0.0625f)   // |v| < 0.25: odd series keeps RELATIVE accuracy where 1 - 2/(e+1) cancels
+    return v * (1.0f + v2 * (-0.33333334f + v2 * (0.13333334f + v2 * (-0.053968254f + v2 * 0.021869488f))));
+  const float e = __expf(2.0f * v);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == LPG_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == LPG_ACT_TANH) return tanhf(v);
+  if (act == LPG_ACT_TANH) return fast_tanh(v);
   return v;
 }
 

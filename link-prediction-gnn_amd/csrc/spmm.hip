@@ -33,7 +33,7 @@ constexpr int kDefaultChunk = 512;  // edges per group chunk
 // LPG_SPMM_BLOCK = threads per workgroup, LPG_SPMM_MODE = 2 gather-only (debug upper bound: no row
 // flushes, results are WRONG).  Defaults are the tuned values.
 struct Tune {
-  int chunk, mode, lds, block;
+  int chunk, mode, lds, block, off32;
   Tune() {
     const char* c = getenv("LPG_SPMM_CHUNK");
     const char* m = getenv("LPG_SPMM_MODE");
@@ -42,6 +42,8 @@ struct Tune {
     mode = m ? atoi(m) : 0;
     const char* l = getenv("LPG_SPMM_LDS");
     lds = l ? atoi(l) : -1;   // -1 = automatic
+    const char* o32 = getenv("LPG_SPMM_OFF32");
+    off32 = o32 ? atoi(o32) : 1;       // 0 disables the 32-bit gather offsets (A/B)
     const char* bb = getenv("LPG_SPMM_BLOCK");
     block = bb ? atoi(bb) : kBlock;
     if (block != 64 && block != 128 && block != 256) block = kBlock;
@@ -76,6 +78,7 @@ struct SpmmArgs {
   float* carry;   // [2 * n_chunks_cap][dpad]
   int64_t dpad;
   int chunk;      // edges per chunk
+  int off32;      // x spans < 4 GiB: gather addresses are base + 32-bit byte offset (1 VALU instead of 6)
 };
 
 // ---- 16-byte (or scalar) row pieces ---------------------------------------------------------
@@ -151,6 +154,18 @@ __device__ __forceinline__ void carry_add(const float* p, float (&acc)[VEC]) {
   }
 }
 
+// Main-kernel flush: bias lives in registers (loaded once per kernel) and the row scale arrives by
+// shuffle from the per-batch prefetch, so a flush issues NO loads -- a load at a flush site makes
+// the compiler wait vmcnt(0) there, draining the gathers in flight (+38 % on the GCN shape).
+template <typename T, int VEC, int ACT>
+__device__ __forceinline__ void store_out_regs(const SpmmArgs& a, int64_t row, int64_t c0, const float (&acc)[VEC],
+                                               const float (&bias)[VEC], float rs) {
+  float o[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) o[i] = apply_act(fmaf(acc[i], rs, bias[i]), ACT);   // ACT is a compile-time constant
+  Piece<T, VEC>::store(static_cast<T*>(a.y) + row * a.ldy + c0, o);
+}
+
 template <typename T, int VEC, bool EPI = true>
 __device__ __forceinline__ void store_out(const SpmmArgs& a, int64_t row, int64_t c0, const float (&acc)[VEC]) {
   if constexpr (!EPI) {      // plain Y = A @ X: no row scale, bias or activation
@@ -170,8 +185,11 @@ __device__ __forceinline__ void store_out(const SpmmArgs& a, int64_t row, int64_
 }
 
 // ---- main kernel -----------------------------------------------------------------------------
-template <typename T, int VEC, int G, bool WEIGHTED, bool EPI, int UREQ, int MODE>
+// EPIK: 0 = plain A @ X; 1/2/3 = epilogue (row scale, bias) with activation none / relu / tanh baked in,
+// so a flush site carries only the code it needs (the flush code is replicated at 8 unrolled sites).
+template <typename T, int VEC, int G, bool WEIGHTED, int EPIK, int UREQ, int MODE>
 __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
+  constexpr bool EPI = EPIK != 0;
   constexpr int GPW = kWave / G;            // groups (chunks) per wave
   constexpr int U = G < UREQ ? G : UREQ;    // row gathers in flight per group step
   const int kChunk = a.chunk;
@@ -201,6 +219,26 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
   float* carry0 = a.carry + (2 * chunk) * a.dpad + c0;
+  float bias_r[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) bias_r[i] = 0.f;
+  if constexpr (EPI) {
+    if (a.bias && lane_on) {
+      if constexpr (VEC % 4 == 0) {               // c0 % 4 == 0 and torch allocations are 16-byte aligned
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) {
+          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + c0 + i);
+          bias_r[i] = b4.x; bias_r[i + 1] = b4.y; bias_r[i + 2] = b4.z; bias_r[i + 3] = b4.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) bias_r[i] = a.bias[c0 + i];
+      }
+    }
+    // pin the values here: hipcc would otherwise sink the loads into every flush site
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) asm volatile("" : "+v"(bias_r[i]));
+  }
 
   // REP: bit pattern selecting steps [0, U) of every group in the 64-bit ballot
   unsigned long long rep = 0;
@@ -213,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
   // next batch's words are requested before the current batch's gathers, so the gather of batch
   // b+1 never waits on an index round trip (one wave per SIMD: nobody else hides that latency)
   constexpr bool PREFETCH = (MODE & 1) != 0;
-  auto load_idx = [&](int base, int& c, int& r, int& rn, float& w) {
+  auto load_idx = [&](int base, int& c, int& r, int& rn, float& w, float& rs) {
     const bool in = base + gl < n_e;
     const int64_t e = start + base + gl;
     c = in ? a.col[e] : 0;
@@ -221,18 +259,19 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
     rn = (in && e + 1 < E) ? a.rowid[e + 1] : -2;
     w = 0.f;
     if constexpr (WEIGHTED) w = in ? a.val[e] : 0.f;
+    rs = 1.f;
   };
   int c, r, rn, c_n = 0, r_n = -1, rn_n = -2;
-  float w, w_n = 0.f;
-  load_idx(0, c, r, rn, w);
+  float w, w_n = 0.f, rs, rs_n = 1.f;
+  load_idx(0, c, r, rn, w, rs);
 
 #pragma unroll 1
   for (int base = 0; base < kChunk; base += G) {
     if (!__any(base < n_e)) break;
     if constexpr (PREFETCH) {
-      if (base + G < kChunk) load_idx(base + G, c_n, r_n, rn_n, w_n);
+      if (base + G < kChunk) load_idx(base + G, c_n, r_n, rn_n, w_n, rs_n);
     } else if (base > 0) {
-      load_idx(base, c, r, rn, w);
+      load_idx(base, c, r, rn, w, rs);
     }
     const bool in = base + gl < n_e;
     const bool fl = in && r != rn;                   // a row ends at this lane's edge
@@ -243,10 +282,21 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
     for (int j0 = 0; j0 < G; j0 += U) {
       if (!__any(base + j0 < n_e)) break;            // chunk shorter than the group width
       typename Piece<T, VEC>::Raw raw[U];
+      if (a.off32) {          // wave-uniform: with one wave per SIMD the address VALU is on the critical path
+        const char* xbytes = static_cast<const char*>(a.x);
+        const uint32_t row_bytes = static_cast<uint32_t>(a.ldx) * sizeof(T);
+        const uint32_t lane_bytes = static_cast<uint32_t>(c0) * sizeof(T);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int cj = __shfl(c, j0 + u, G);
-        raw[u] = Piece<T, VEC>::load(xb + static_cast<int64_t>(cj) * a.ldx);
+        for (int u = 0; u < U; ++u) {
+          const uint32_t cj = static_cast<uint32_t>(__shfl(c, j0 + u, G));
+          raw[u] = Piece<T, VEC>::load(reinterpret_cast<const T*>(xbytes + (cj * row_bytes + lane_bytes)));
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int cj = __shfl(c, j0 + u, G);
+          raw[u] = Piece<T, VEC>::load(xb + static_cast<int64_t>(cj) * a.ldx);
+        }
       }
       const bool any_flush = (fmask & (rep << j0)) != 0ull;      // scalar test
       if ((MODE & 2) != 0 || (wave_full && !any_flush)) {
@@ -280,11 +330,16 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
           }
           if ((mym >> (j0 + u)) & 1ull) {            // a row ends at this edge (group-uniform)
             const int rj = __shfl(r, j0 + u, G);
+            float rsj = 1.f;                         // the row scale is read at the (rare) flush itself; callers that
+            if constexpr (EPI)                       // can fold it into the edge weights instead (SEAL's D^-1) do so
+              if (a.row_scale) rsj = a.row_scale[rj];
             if (lane_on) {
               if (first_seg && open_left)
                 carry_store<VEC>(carry0, acc);        // last piece of a row begun in an earlier chunk
+              else if constexpr (EPI)
+                store_out_regs<T, VEC, EPIK - 1>(a, rj, c0, acc, bias_r, rsj);
               else
-                store_out<T, VEC, EPI>(a, rj, c0, acc);
+                store_out<T, VEC, false>(a, rj, c0, acc);
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -293,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
         }
       }
     }
-    if constexpr (PREFETCH) { c = c_n; r = r_n; rn = rn_n; w = w_n; }
+    if constexpr (PREFETCH) { c = c_n; r = r_n; rn = rn_n; w = w_n; rs = rs_n; }
   }
   if (open_right && lane_on) carry_store<VEC>(carry0 + ((first_seg && open_left) ? 0 : a.dpad), acc);
 }
@@ -381,16 +436,21 @@ int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
   LPG_REQUIRE(n_blocks < (int64_t(1) << 31) && tiles < 65536, "csr_spmm: grid too large");
   dim3 grid(static_cast<unsigned>(n_blocks), static_cast<unsigned>(tiles));
   const bool epi = a.row_scale || a.bias || a.act != LPG_ACT_NONE;
-#define LPG_LAUNCH_MAIN(W, EP, MD) \
-  hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, W, EP, 8, MD>), grid, blk, lds, st, a)
+#define LPG_LAUNCH_MAIN(W, EPK, MD) \
+  hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, W, EPK, 8, MD>), grid, blk, lds, st, a)
+  static_assert(LPG_ACT_NONE == 0 && LPG_ACT_RELU == 1 && LPG_ACT_TANH == 2, "EPIK = 1 + act");
   if (tn.mode == 2 && !a.val && !epi) {
-    LPG_LAUNCH_MAIN(false, false, 2);          // debug: gather-only upper bound (wrong results)
+    LPG_LAUNCH_MAIN(false, 0, 2);              // debug: gather-only upper bound (wrong results)
   } else if (tn.mode == 1 && !a.val && !epi) {
-    LPG_LAUNCH_MAIN(false, false, 1);          // index prefetch variant
-  } else if (a.val) {
-    if (epi) LPG_LAUNCH_MAIN(true, true, 0); else LPG_LAUNCH_MAIN(true, false, 0);
+    LPG_LAUNCH_MAIN(false, 0, 1);              // index prefetch variant
+  } else if (!epi) {
+    if (a.val) LPG_LAUNCH_MAIN(true, 0, 0); else LPG_LAUNCH_MAIN(false, 0, 0);
+  } else if (a.act == LPG_ACT_NONE) {
+    if (a.val) LPG_LAUNCH_MAIN(true, 1, 0); else LPG_LAUNCH_MAIN(false, 1, 0);
+  } else if (a.act == LPG_ACT_RELU) {
+    if (a.val) LPG_LAUNCH_MAIN(true, 2, 0); else LPG_LAUNCH_MAIN(false, 2, 0);
   } else {
-    if (epi) LPG_LAUNCH_MAIN(false, true, 0); else LPG_LAUNCH_MAIN(false, false, 0);
+    if (a.val) LPG_LAUNCH_MAIN(true, 3, 0); else LPG_LAUNCH_MAIN(false, 3, 0);
   }
 #undef LPG_LAUNCH_MAIN
   hipLaunchKernelGGL((spmm_fixup_kernel<T, VEC, G>), grid, blk, 0, st, a);
@@ -411,7 +471,7 @@ int launch_vec(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
 
 template <typename T, int WIDE>
 int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val, const T* x,
-               int64_t ldx, T* y, int64_t ldy, int64_t N, int64_t e_cap, int64_t d, const float* row_scale,
+               int64_t ldx, T* y, int64_t ldy, int64_t N, int64_t n_cols, int64_t e_cap, int64_t d, const float* row_scale,
                const float* bias, int act, int64_t n_empty_hint, void* workspace, int64_t workspace_bytes,
                void* stream) {
   LPG_REQUIRE(N >= 0 && e_cap >= 0 && d >= 1, "csr_spmm: bad sizes N=%lld e_cap=%lld d=%lld", (long long)N,
@@ -437,6 +497,8 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
   a.carry = static_cast<float*>(workspace);
   a.dpad = align_up(d, 4);
   a.chunk = chunk_for(e_cap);
+  a.off32 = (n_cols > 0 && static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * sizeof(T) <= (uint64_t(1) << 32)) ? 1 : 0;
+  if (!tune().off32) a.off32 = 0;
   if (e_cap > 0) {
     const bool wide = d % WIDE == 0 && ldx % WIDE == 0 && ldy % WIDE == 0 &&
                       reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
@@ -461,17 +523,17 @@ LPG_EXPORT int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d) {
 }
 
 LPG_EXPORT int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,
-                                const float* x, int64_t ldx, float* y, int64_t ldy, int64_t N, int64_t e_cap,
-                                int64_t d, const float* row_scale, const float* bias, int act, int64_t n_empty_hint,
-                                void* workspace, int64_t workspace_bytes, void* stream) {
-  return spmm_entry<float, 4>(plan, rowptr, col, val, x, ldx, y, ldy, N, e_cap, d, row_scale, bias, act, n_empty_hint,
+                                const float* x, int64_t ldx, float* y, int64_t ldy, int64_t N, int64_t n_cols,
+                                int64_t e_cap, int64_t d, const float* row_scale, const float* bias, int act,
+                                int64_t n_empty_hint, void* workspace, int64_t workspace_bytes, void* stream) {
+  return spmm_entry<float, 4>(plan, rowptr, col, val, x, ldx, y, ldy, N, n_cols, e_cap, d, row_scale, bias, act, n_empty_hint,
                               workspace, workspace_bytes, stream);
 }
 
 LPG_EXPORT int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,
-                                 const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t N, int64_t e_cap,
-                                 int64_t d, const float* row_scale, const float* bias, int act, int64_t n_empty_hint,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
-  return spmm_entry<uint16_t, 8>(plan, rowptr, col, val, x, ldx, y, ldy, N, e_cap, d, row_scale, bias, act,
+                                 const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t N, int64_t n_cols,
+                                 int64_t e_cap, int64_t d, const float* row_scale, const float* bias, int act,
+                                 int64_t n_empty_hint, void* workspace, int64_t workspace_bytes, void* stream) {
+  return spmm_entry<uint16_t, 8>(plan, rowptr, col, val, x, ldx, y, ldy, N, n_cols, e_cap, d, row_scale, bias, act,
                                  n_empty_hint, workspace, workspace_bytes, stream);
 }

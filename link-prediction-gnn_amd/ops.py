@@ -201,7 +201,7 @@ class CSRGraph:
         val = self.val if use_val else None
         ws, nbytes = self._workspace(d)
         args = (_ptr(self._plan), _ptr(self.rowptr), _ptr(self.col), _ptr(val), _ptr(x), x.stride(0), _ptr(out),
-                out.stride(0), self.n_rows, self.e_cap, d, _ptr(row_scale), _ptr(bias), ACT[act], self.n_empty,
+                out.stride(0), self.n_rows, self.n_cols, self.e_cap, d, _ptr(row_scale), _ptr(bias), ACT[act], self.n_empty,
                 _ptr(ws), nbytes, _stream())
         if x.dtype == torch.float32:
             _lib.check(lib.lpg_csr_spmm_f32(*args), "csr_spmm_f32")

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-KEYS = ["LPG_SPMM_CHUNK", "LPG_SPMM_U", "LPG_SPMM_MODE", "LPG_SPMM_LDS", "LPG_SPMM_PIPE", "LPG_SPMM_BLOCK"]
+KEYS = ["LPG_SPMM_CHUNK", "LPG_SPMM_U", "LPG_SPMM_MODE", "LPG_SPMM_LDS", "LPG_SPMM_PIPE", "LPG_SPMM_BLOCK", "LPG_SPMM_OFF32"]
 variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[1:]] or [{}]
 dev = torch.device("cuda:0")
 N, E, d = 5_000_000, 100_000_000, int(os.environ.get("SWEEP_D", "128"))
