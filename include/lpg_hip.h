@@ -200,10 +200,13 @@ int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_
 /* Block-diagonal CSR of A~ = A + I over a batch, D^-1 = 1/rowsum(A~), and
  * X = [onehot(tag_map[tag], T) || emb[node]]  [SEAL/config/data.py:94-140].
  * node_off[B+1] = exclusive scan of n_nodes (host-computed or torch.cumsum);
- * edge capacity e_cap >= sum_b (nnz_b + n_b).  rowptr gets sum(n)+1 entries. */
+ * edge capacity e_cap >= sum_b (nnz_b + n_b).  rowptr gets sum(n)+1 entries.
+ * fold_dinv != 0: the stored values are D^-1 A~ (each row's scale folded into its edges), so the
+ * SpMM needs no per-row scale load: tanh((D^-1 A~) H) == tanh(D^-1 (A~ H)). */
 int lpg_seal_block_csr(const int32_t* n_nodes, const int64_t* node_off, const uint32_t* adj_bits,
                        int64_t B, int64_t* rowptr, int32_t* col, float* val, float* d_inv,
-                       int64_t e_cap, void* workspace, int64_t workspace_bytes, void* stream);
+                       int64_t e_cap, int fold_dinv, void* workspace, int64_t workspace_bytes,
+                       void* stream);
 int64_t lpg_seal_block_csr_bytes(int64_t total_nodes);
 int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_nodes, const int64_t* node_off,
                           const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len,

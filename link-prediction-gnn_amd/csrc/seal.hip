@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void seal_fill_kernel(const int64_t* __rest
                                                            const uint32_t* __restrict__ adj_bits, int64_t B,
                                                            int64_t total, const int64_t* __restrict__ rowptr,
                                                            int32_t* __restrict__ col, float* __restrict__ val,
-                                                           int64_t e_cap) {
+                                                           int64_t e_cap, int fold_dinv) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; g < total; g += stride) {
     const int64_t b = graph_of(node_off, B, g);
@@ -328,23 +328,31 @@ __global__ __launch_bounds__(kBlock) void seal_fill_kernel(const int64_t* __rest
     const uint32_t* row = adj_bits + (b * MAXN + i) * WORDS;
     int64_t k = rowptr[g];
     bool diag_done = false;
+    float one = 1.f;                 // fold_dinv: the stored values are D^-1 A~ (row scale folded into the edges)
+    if (fold_dinv) {
+      int pc = 0;
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) pc += __popc(row[w]);
+      one = static_cast<float>(1.0 / static_cast<double>(pc + 1));
+    }
+    const float two = 2.f * one;
     for (int w = 0; w < WORDS; ++w) {
       uint32_t m = row[w];
       while (m) {
         const int j = (w << 5) + __ffs(m) - 1;
         m &= m - 1;
         if (!diag_done && j > i) {                  // diagonal not set in A: insert the +I entry in order
-          if (k < e_cap) { col[k] = static_cast<int32_t>(base + i); val[k] = 1.f; }
+          if (k < e_cap) { col[k] = static_cast<int32_t>(base + i); val[k] = one; }
           ++k;
           diag_done = true;
         }
-        if (k < e_cap) { col[k] = static_cast<int32_t>(base + j); val[k] = (j == i) ? 2.f : 1.f; }
+        if (k < e_cap) { col[k] = static_cast<int32_t>(base + j); val[k] = (j == i) ? two : one; }
         if (j == i) diag_done = true;
         ++k;
       }
     }
     if (!diag_done) {
-      if (k < e_cap) { col[k] = static_cast<int32_t>(base + i); val[k] = 1.f; }
+      if (k < e_cap) { col[k] = static_cast<int32_t>(base + i); val[k] = one; }
     }
   }
 }
@@ -446,7 +454,7 @@ LPG_EXPORT int64_t lpg_seal_block_csr_bytes(int64_t total_nodes) {
 // Phase 1 (col == NULL): rowptr[total+1] and d_inv[total].  Phase 2 (col != NULL): fill col/val.
 LPG_EXPORT int lpg_seal_block_csr(const int32_t* n_nodes, const int64_t* node_off, const uint32_t* adj_bits, int64_t B,
                                   int64_t* rowptr, int32_t* col, float* val, float* d_inv, int64_t e_cap,
-                                  void* workspace, int64_t workspace_bytes, void* stream) {
+                                  int fold_dinv, void* workspace, int64_t workspace_bytes, void* stream) {
   LPG_REQUIRE(B >= 0 && node_off && rowptr, "seal_block_csr: bad argument");
   (void)n_nodes;
   hipStream_t st = as_stream(stream);
@@ -469,7 +477,7 @@ LPG_EXPORT int lpg_seal_block_csr(const int32_t* n_nodes, const int64_t* node_of
   } else {
     LPG_REQUIRE(val && adj_bits, "seal_block_csr: null pointer");
     if (total > 0)
-      hipLaunchKernelGGL(seal_fill_kernel, dim3(grid_for(total)), dim3(kBlock), 0, st, node_off, adj_bits, B, total, rowptr, col, val, e_cap);
+      hipLaunchKernelGGL(seal_fill_kernel, dim3(grid_for(total)), dim3(kBlock), 0, st, node_off, adj_bits, B, total, rowptr, col, val, e_cap, fold_dinv);
   }
   return check_launch("seal_block_csr");
 }

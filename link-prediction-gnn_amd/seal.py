@@ -205,9 +205,11 @@ def compact_tag_map(batch):
     return tag_map, T
 
 
-def gnn_inputs(batch, tag_map, tags_size, emb=None):
+def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True):
     """SEAL/config/data.py:94-140 batched: block-diagonal A~ = A + I (CSR, values 1 / 2),
-    D^-1 = 1/rowsum(A~) per vertex, X = [onehot(tag) || emb[node]].  Returns (CSRGraph, d_inv, X)."""
+    D^-1 = 1/rowsum(A~) per vertex, X = [onehot(tag) || emb[node]].  Returns (CSRGraph, d_inv, X).
+    fold_dinv (default): the CSR values are D^-1 A~, so graph_conv_stack needs no per-row scale in the
+    SpMM epilogue (a load at a row flush drains the gathers in flight); d_inv is still returned."""
     lib = _lib.load()
     dev = batch.n.device
     off = batch.node_off()
@@ -217,16 +219,17 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None):
     rowptr = torch.empty(total + 1, dtype=torch.int64, device=dev)
     d_inv = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
     P, S = _ops._ptr, _ops._stream
-    _lib.check(lib.lpg_seal_block_csr(P(batch.n), P(off), P(batch.adj_bits), batch.B, P(rowptr), 0, 0, P(d_inv), 0,
+    _lib.check(lib.lpg_seal_block_csr(P(batch.n), P(off), P(batch.adj_bits), batch.B, P(rowptr), 0, 0, P(d_inv), 0, 0,
                                       P(ws), nbytes, S()), "seal_block_csr(count)")
     nnz = int(rowptr[-1].item())
     col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
     val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
     _lib.check(lib.lpg_seal_block_csr(P(batch.n), P(off), P(batch.adj_bits), batch.B, P(rowptr), P(col), P(val),
-                                      P(d_inv), nnz, P(ws), nbytes, S()), "seal_block_csr(fill)")
+                                      P(d_inv), nnz, int(fold_dinv), P(ws), nbytes, S()), "seal_block_csr(fill)")
     g = _ops.CSRGraph(rowptr, col[:nnz] if nnz else col, val[:nnz] if nnz else val, total, total, nnz)
     g._build_plan()
     g.n_empty = 0                       # A~ = A + I: every row holds its diagonal
+    g.rows_prescaled = bool(fold_dinv)
     emb_dim = 0 if emb is None else emb.shape[1]
     emb = None if emb is None else _ops._c(emb, torch.float32)
     x = torch.empty((total, tags_size + emb_dim), dtype=torch.float32, device=dev)
@@ -243,7 +246,8 @@ def graph_conv_stack(g, d_inv, x, weights):
     z, zs = x, []
     for w in weights:                                             # x bf16 => the whole stack runs in bf16 storage
         h = _ops.linear(z, w, w_is_km=True)                       # K5 on the matrix cores (fp32 or bf16 MFMA)
-        z = g.spmm(h, row_scale=d_inv, act="tanh")                # K10: one fused kernel per layer
+        rs = None if getattr(g, "rows_prescaled", False) else d_inv
+        z = g.spmm(h, row_scale=rs, act="tanh")                   # K10: one fused kernel per layer
         zs.append(z)
     return torch.cat(zs[:3], dim=1), zs[3][:, 0]
 
