@@ -378,16 +378,17 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
   carry_add<VEC>(a.carry + (2 * first + 1) * a.dpad + c0, acc);
   const float* p = a.carry + c0;
   int64_t c = first + 1;
-  for (; c + 4 <= chunk + 1; c += 4) {              // 4 partial rows in flight, added in order
-    float t[4][VEC];
+  constexpr int FU = VEC >= 4 ? 16 : 8;             // partial rows in flight (a star row is a 40 K-long chain)
+  for (; c + FU <= chunk + 1; c += FU) {             // loaded together, added in chunk order
+    float t[FU][VEC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < FU; ++u) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) t[u][i] = 0.f;
       carry_add<VEC>(p + 2 * (c + u) * a.dpad, t[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < FU; ++u)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += t[u][i];
   }

@@ -789,3 +789,38 @@ def test_spmm_bit_exact_vs_same_order_c_loop(dev, d, weighted):
     rowptr, col, val, _ = agg.coo_to_csr(ei[1], ei[0], n_rows, w)
     want = spmm_c.spmm_f32_chunked(rowptr, col, val, x, chunk)
     assert np.array_equal(y, want), float(np.abs(y - want).max())
+
+
+def test_zero_size_inputs_everywhere(dev):
+    """empty inputs through every public op: no launch, no fault, well-formed empty/zero outputs."""
+    import lpgnn_amd
+    from lpgnn_amd import ops, twowl, seal
+    from lpgnn_amd.torch_scatter import scatter_add
+    from lpgnn_amd.torch_sparse import spmm
+    z64 = torch.zeros(0, dtype=torch.int64, device=dev)
+    assert scatter_add(z64, z64, dim_size=5).tolist() == [0] * 5
+    assert scatter_add(torch.zeros((0, 3), device=dev), z64, dim=0, dim_size=2).shape == (2, 3)
+    assert twowl.degree(torch.zeros((2, 0), dtype=torch.int64, device=dev), 4).tolist() == [0, 0, 0, 0]
+    g = lpgnn_amd.CSRGraph.from_edge_index(torch.zeros((2, 0), dtype=torch.int64, device=dev), 6, 6)
+    y = g.spmm(torch.randn(6, 8, device=dev), bias=torch.ones(8, device=dev), act="relu")
+    assert torch.equal(y, torch.ones(6, 8, device=dev))                      # act(bias) on empty rows
+    assert spmm(torch.zeros((2, 0), dtype=torch.int64, device=dev), torch.zeros(0, device=dev), 3, 4,
+                torch.randn(4, 2, device=dev)).abs().sum() == 0
+    gg = lpgnn_amd.CSRGraph.from_edge_index(torch.zeros((2, 0), dtype=torch.int64, device=dev), 5, 5, gcn_self_loops=True)
+    gg.gcn_normalize_()                                                       # only self loops: A_hat = I
+    x = torch.randn(5, 4, device=dev)
+    assert torch.allclose(gg.spmm(x), x)
+    assert ops.linear(torch.zeros((0, 4), device=dev), torch.randn(3, 4, device=dev)).shape == (0, 3)
+    assert ops.pair_gather_mul(torch.randn(3, 4, device=dev), torch.zeros((0, 2), dtype=torch.int64, device=dev)).shape == (0, 4)
+    assert ops.pair_readout(torch.randn(3, 4, device=dev), z64, torch.randn(1, 4, device=dev), torch.zeros(1, device=dev)).shape == (0, 1)
+    assert ops.embedding(torch.randn(3, 4, device=dev), z64).shape == (0, 4)
+    e, er = ops.flip_index(torch.zeros((2, 0), dtype=torch.int64, device=dev))
+    assert e.shape == (2, 0) and er.shape == (2, 0)
+    assert twowl.get_ei2(4, torch.zeros((2, 0), dtype=torch.int64, device=dev),
+                         torch.zeros((2, 0), dtype=torch.int64, device=dev)).shape == (2, 0)
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]], device=dev)
+    ei_new, x_new, _ = twowl.sample_block(z64, 3, ei, None)
+    assert torch.equal(ei_new, ei) and x_new.tolist() == [1, 1, 1]
+    graph = seal.build_train_csr(np.array([[0, 1], [1, 2]]), 3, test_ratio=0.0, device=dev)
+    b = seal.extract_subgraphs(np.zeros((0, 2), dtype=np.int64), graph, 1)
+    assert b.B == 0 and b.n.numel() == 0
