@@ -28,7 +28,10 @@ def _rows_view(src, index, dim):
     if index.dim() == 1 and src.dim() >= 1 and (dim == 0 or src.dim() == 1):
         if index.numel() != src.shape[dim]:
             raise ValueError("scatter_add: index length does not match src along dim")
-        return dim, src.reshape(src.shape[0], -1) if src.dim() > 1 else src, index, None
+        cols = 1
+        for v in src.shape[1:]:
+            cols *= int(v)
+        return dim, src.reshape(src.shape[0], cols) if src.dim() > 1 else src, index, None
     # general case: index broadcast to src (torch_scatter.utils.broadcast), element-wise scatter
     idx = index
     if idx.dim() == 1:
@@ -42,7 +45,10 @@ def _rows_view(src, index, dim):
 def _impl_into(src, index, dim, out):
     dim, s, idx, general = _rows_view(src, index, dim)
     if general is None:
-        o = out.view(out.shape[0], -1) if out.dim() > 1 else out
+        cols = 1
+        for v in out.shape[1:]:
+            cols *= int(v)
+        o = out.view(out.shape[0], cols) if out.dim() > 1 else out
         if not o.is_contiguous():
             raise ValueError("scatter_add: `out` must be contiguous")
         _ops.scatter_add_rows(s, idx, o)
