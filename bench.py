@@ -230,6 +230,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=4, help="pipeline stages for compute/collective overlap (N > 1)")
     ap.add_argument("--collective", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
                     help="how the per-rank partial aggregates are summed (N > 1); see lpgnn_amd/dist.py")
+    ap.add_argument("--partition", default="source", choices=["source", "dst"],
+                    help="source: the north star's source-edge partition + RCCL reduction (default). dst: every rank "
+                         "owns the destination rows of its range and a replica of X -- no reduction at all (SURVEY 8e's "
+                         "labelled alternative; deviates from the prescribed scheme)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-twowl", action="store_true")
     args = ap.parse_args()
@@ -257,7 +261,21 @@ def main():
 
     t_build = time.time()
     force_dist = os.environ.get("LPG_BENCH_FORCE_DIST") == "1"     # rehearse the N > 1 code path on one GPU
-    if world == 1 and not force_dist:
+    if world > 1 and args.partition == "dst":
+        # destination-row partition: rank g aggregates the |E| edges that ENTER its row range from a full
+        # replica of X (V*d*4 B = 2.56 GB -- nothing at 288 GB); the rows it produces are final, no exchange
+        from lpgnn_amd import dist as ldist
+        lo, hi = ldist.source_range(N, world, rank)
+        ei = rmat_edges(N, E, 5 + rank, device)
+        ei[1] = ei[1] % (hi - lo)                                     # destinations local to the owned range
+        import lpgnn_amd as _l
+        g = _l.CSRGraph.from_edge_index(ei, hi - lo, N)
+        del ei
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1005)
+        x = torch.randn((N, d), generator=gen, device=device).to(dtype)
+        runner = None
+    elif world == 1 and not force_dist:
         g, x = make_rmat_problem(N, E, d, seed=5, device=device, dtype=dtype)
         runner = None
     else:
@@ -312,12 +330,15 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"RMAT(0.57,0.19,0.19,0.05) CSR-SpMM |V|={N} |E|={E}/GPU d={d} {args.dtype}, unweighted, "
                                "int32 col / int64 rowptr; north_star 1-GPU target instance (SURVEY 8d config 5 generator, seed 5)",
-                   "parallelism": "single GPU" if world == 1 else f"source-edge partition x{world} + RCCL {args.collective} of the "
-                                                                    f"partial Y[V,d] ({args.blocks} stages, overlapped with the SpMM)",
+                   "parallelism": "single GPU" if world == 1 else (
+                       f"destination-row partition x{world}, X replicated, no collective (labelled alternative)"
+                       if args.partition == "dst" else
+                       f"source-edge partition x{world} + RCCL {args.collective} of the partial Y[V,d] "
+                       f"({args.blocks} stages, overlapped with the SpMM)"),
                    "graph_build_s": t_build},
     }
     if rank == 0:
-        if runner is None:
+        if runner is None and world == 1:
             alg = spmm_algorithmic_bytes(N, nnz, d, elt)
             ach = alg / (kern_ms * 1e-3) / 1e9
             traffic = None
