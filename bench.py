@@ -364,6 +364,15 @@ def main():
                         out[key] = fn(device)
                     except Exception as e:   # secondary figures must never take the headline down
                         out[key] = {"error": repr(e)}
+        elif world > 1:
+            # rank 0's share: the local SpMM's algorithmic bytes over the WHOLE step (collective included when the
+            # partition has one), so frac here is a lower bound on the kernel's own
+            alg = spmm_algorithmic_bytes(N if runner is not None else g.n_rows, nnz, d, elt)
+            ach = alg / (kern_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "rank 0: lpg_csr_spmm stages + the step's collective (HIP-event time of the whole step)",
+                               "algorithmic_bytes_per_step": alg, "avg_launch_ms": kern_ms}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
