@@ -218,6 +218,60 @@ def seal_forward_bench(device, iters=10):
             "reference_recorded_subgraph_passes_per_s": 2150}
 
 
+def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5):
+    """configs[2]/[3] stand-in, SURVEY 8e (i): "ogbl-collab"-shaped synthetic SEAL scoring forward with the
+    candidate pairs sharded across ranks (graph + features replicated, no data-path collective; the [B] scores
+    are all-gathered at the end).  RMAT |V| = 235 868, 1 285 465 undirected edges (seed 1), 100 K candidate
+    pairs PER GPU (weak scaling), hop 1, cap 100, X = [onehot(DRNL) || 128-d], random-init weights of the
+    reference's DGCNN (no checkpoint exists at this width)."""
+    from lpgnn_amd import seal
+    from lpgnn_amd import dist as ldist
+    N, E, D, k = 235_868, 1_285_465, 128, 18
+    ei = rmat_edges(N, E, 1, device)
+    graph = seal.build_train_csr(ei.t().cpu().numpy(), N, test_ratio=0.0, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(2)
+    B = pairs_per_gpu * world
+    pairs = torch.randint(0, N, (B, 2), generator=gen, device=device)          # identical on every rank
+    emb = torch.randn((N, D), generator=gen, device=device)
+    # the tag vocabulary is a property of the WHOLE candidate set (SEAL/config/subgraph.py:90-101 compacts tags
+    # globally), so it is fitted once over all pairs, outside the timed region, identically on every rank
+    tag_map, T = seal.compact_tag_map(seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0))
+    torch.manual_seed(0)
+    gw = [torch.randn(a, b, device=device) * 0.1 for a, b in ((T + D, 32), (32, 32), (32, 32), (32, 1))]
+    hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, device=device) * 0.1,
+          "conv1d_kernel_2": torch.randn(5, 16, 32, device=device) * 0.1,
+          "weight_1": torch.randn((k - 4) * 32, 128, device=device) * 0.1, "bias_1": torch.zeros(128, device=device),
+          "weight_2": torch.randn(128, 2, device=device), "bias_2": torch.zeros(2, device=device)}
+
+    def score_fn(p):
+        batch = seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=0)
+        g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb)
+        z, key = seal.graph_conv_stack(g, d_inv, x, gw)
+        return seal.head(z, key, batch.node_off(), hw)[1]
+
+    scorer = ldist.ShardedLinkScorer(score_fn, world=world, rank=rank)
+    s = scorer(pairs)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        s = scorer(pairs)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / iters
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert s.shape[0] == B
+    return {"workload": f"synthetic collab-shaped SEAL scoring forward: |V|={N}, {E} undirected edges, {pairs_per_gpu} candidate "
+                        f"pairs per GPU x {world}, hop 1, d={D} fp32, pairs sharded across ranks + all_gather of scores",
+            "scored_edges": B, "ms_per_forward": dt * 1e3, "scored_edges_per_s": B / dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,6 +374,7 @@ def main():
     per_step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     kern_ms = sum(per_step_ms) / len(per_step_ms)
     nnz = g.nnz() if g is not None else runner.nnz()
+    runner_was_none, g_rows = runner is None, (g.n_rows if g is not None else N)
     total_edges = nnz * world
     value = total_edges * args.steps / elapsed
 
@@ -337,8 +392,21 @@ def main():
                        f"({args.blocks} stages, overlapped with the SpMM)"),
                    "graph_build_s": t_build},
     }
+    seal_sharded = None
+    if not args.no_twowl:
+        del y
+        g = runner = x = None                    # the SpMM operands are done; free HBM before the secondary figure
+        torch.cuda.empty_cache()
+        try:
+            seal_sharded = seal_sharded_bench(device, world, rank, dist)
+        except Exception as e:                   # (a rank that raises here leaves the others at a barrier: the
+            seal_sharded = {"error": repr(e)}    #  launcher's timeout ends the job; the headline line is lost too)
+            if world > 1:
+                raise
     if rank == 0:
-        if runner is None and world == 1:
+        if seal_sharded is not None:
+            out["seal_sharded"] = seal_sharded
+        if runner_was_none and world == 1:
             alg = spmm_algorithmic_bytes(N, nnz, d, elt)
             ach = alg / (kern_ms * 1e-3) / 1e9
             traffic = None
@@ -367,7 +435,7 @@ def main():
         elif world > 1:
             # rank 0's share: the local SpMM's algorithmic bytes over the WHOLE step (collective included when the
             # partition has one), so frac here is a lower bound on the kernel's own
-            alg = spmm_algorithmic_bytes(N if runner is not None else g.n_rows, nnz, d, elt)
+            alg = spmm_algorithmic_bytes(g_rows, nnz, d, elt)
             ach = alg / (kern_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": None,

@@ -165,8 +165,10 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
             if (u != v) s_list[1] = ListPlan{v, static_cast<int>(dv), dv, 1, 0};
           } else {
             // deterministic stand-in for np.random.shuffle: visiting order and the kept neighbours
-            // come from a counter-based hash of (seed, pair index)
-            const uint64_t h = mix64(seed ^ (static_cast<uint64_t>(b) * 0x9E3779B97F4A7C15ull));
+            // come from a counter-based hash of (seed, u, v) -- of the pair itself, not of its position in
+            // the batch, so a candidate list sharded across GPUs extracts the same subgraphs as one batch
+            const uint64_t h = mix64(seed ^ (((static_cast<uint64_t>(static_cast<uint32_t>(u)) << 32) |
+                                              static_cast<uint32_t>(v)) * 0x9E3779B97F4A7C15ull));
             const bool swap = (h >> 63) != 0;
             const int32_t first = swap ? v : u, second = swap ? u : v;
             const int64_t d1 = swap ? dv : du, d2 = swap ? du : dv;

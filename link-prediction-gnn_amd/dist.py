@@ -164,3 +164,48 @@ class SourcePartitionedSpMM:
             out.copy_(full[: self.n_nodes])
             return out
         return full[: self.n_nodes]
+
+
+class ShardedLinkScorer:
+    """Scored-edge parallelism: candidate pairs are independent units, so
+    rank g scores the contiguous slice ``source_range(B, G, g)`` of the candidate list against a
+    REPLICA of the (small) observed graph; there is no exchange on the data path.  The only
+    communication is the optional gather of the [B] scores at the end (``gather=True``: one
+    all_gather of equal, padded slices -- 4 B per scored edge).
+
+    ``score_fn(pairs_slice [b, 2]) -> scores [b]`` is the single-GPU scorer, e.g. a closure over
+    ``lpgnn_amd.seal.extract_subgraphs / gnn_inputs / graph_conv_stack / head``.
+    """
+
+    def __init__(self, score_fn: Callable, group=None, world=None, rank=None):
+        import torch.distributed as dist
+        ready = dist.is_available() and dist.is_initialized()
+        self.score_fn, self.group = score_fn, group
+        self.world = world if world is not None else (dist.get_world_size(group) if ready else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if ready else 0)
+
+    def my_slice(self, n_pairs: int) -> Tuple[int, int]:
+        return source_range(n_pairs, self.world, self.rank)
+
+    def __call__(self, pairs: torch.Tensor, gather: bool = True) -> torch.Tensor:
+        import torch.distributed as dist
+        B = pairs.shape[0]
+        lo, hi = self.my_slice(B)
+        mine = self.score_fn(pairs[lo:hi])
+        if mine.shape[0] != hi - lo:
+            raise ValueError("ShardedLinkScorer: score_fn must return one score per pair")
+        if not gather or self.world == 1:
+            return mine
+        width = -(-B // self.world)                       # slices differ by at most one pair: pad to the widest
+        send = mine.new_zeros((width,) + tuple(mine.shape[1:]))
+        send[: hi - lo] = mine
+        recv = mine.new_empty((self.world * width,) + tuple(mine.shape[1:]))
+        if dist.get_backend(self.group) == "gloo":        # CPU tests: gloo has no all_gather_into_tensor
+            dist.all_gather(list(recv.view(self.world, width, *mine.shape[1:]).unbind(0)), send, group=self.group)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        parts = []
+        for r in range(self.world):
+            a, b = source_range(B, self.world, r)
+            parts.append(recv[r * width: r * width + (b - a)])
+        return torch.cat(parts)

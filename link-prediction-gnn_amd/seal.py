@@ -58,7 +58,7 @@ def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, r
                       seed=0):
     """Batched extract_subgraph + node_labeling.  pairs int64 [B,2].  `capped` marks the pairs for
     which the reference's RNG-dependent truncation (np.random.shuffle, subgraph.py:122,128) fires:
-      cap_policy="device": the kernel follows the same branch with a hash of (seed, pair index) in
+      cap_policy="device": the kernel follows the same branch with a hash of (seed, u, v) in
                            place of the RNG -- deterministic, no host round trip;
       cap_policy="report": those pairs come back with n = 0; pass node lists through
                            replay_nodes / replay_n to label them in a given order (tests replay the

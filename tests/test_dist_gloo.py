@@ -80,6 +80,47 @@ def test_source_partition_allreduce_world2():
         assert err < 1e-12
 
 
+def _score_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lpgnn_amd import dist as ldist
+    seen = []
+
+    def score_fn(p):                                     # stands in for the single-GPU SEAL scorer
+        seen.append(p.clone())
+        return (p[:, 0] * 1000 + p[:, 1]).to(torch.float32)
+
+    out = {}
+    for B in (11, 8, 1, 0):
+        pairs = torch.arange(2 * B, dtype=torch.int64).view(B, 2)
+        sc = ldist.ShardedLinkScorer(score_fn)
+        got = sc(pairs)
+        out[B] = (got.tolist(), sc.my_slice(B), sc(pairs, gather=False).tolist())
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_scored_edge_sharding_world2():
+    """8e (i): candidate pairs split across ranks, graph replicated, only the [B] scores gathered."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_score_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for B in (11, 8, 1, 0):
+        want = [float(2 * i * 1000 + 2 * i + 1) for i in range(B)]
+        assert res[0][B][0] == want and res[1][B][0] == want          # every rank ends with all scores, in order
+        (a0, b0), (a1, b1) = res[0][B][1], res[1][B][1]
+        assert a0 == 0 and b0 == a1 and b1 == B and abs((b0 - a0) - (b1 - a1)) <= 1
+        assert res[0][B][2] == want[a0:b0] and res[1][B][2] == want[a1:b1]
+
+
 def test_ranges_cover_and_balance():
     from lpgnn_amd import dist as ldist
     for n, w in [(10, 3), (5_000_000, 8), (7, 8), (1, 1)]:

@@ -681,6 +681,15 @@ def test_seal_subgraphs_collab_scale_synthetic(dev):
         assert np.array_equal(_unpack_adj(bits[g], int(n[g])), adj)
         assert tags[g, : n[g]].tolist() == seal_int.node_labeling(adj)
     assert n_unc > 1000
+    # 8e (i): a sharded candidate list extracts exactly what one batch does (the cap policy hashes
+    # the pair, not its position), so ShardedLinkScorer's ranks agree with the single-GPU run
+    from lpgnn_amd import dist as ldist
+    for world in (2, 3):
+        for r in range(world):
+            lo, hi = ldist.source_range(len(pairs), world, r)
+            part = seal.extract_subgraphs(pairs[lo:hi], graph, 1, cap_policy="device", seed=11)
+            assert torch.equal(part.n, batch.n[lo:hi]) and torch.equal(part.nodes, batch.nodes[lo:hi])
+            assert torch.equal(part.tags, batch.tags[lo:hi]) and torch.equal(part.adj_bits, batch.adj_bits[lo:hi])
 
 
 def test_data_path_to_forward_fb_pages_food(dev, golden_dir):
