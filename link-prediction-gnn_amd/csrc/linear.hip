@@ -267,6 +267,11 @@ LPG_EXPORT int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w
   if (n == 0) return LPG_OK;
   LPG_REQUIRE(x && w && y, "linear: null pointer");
   hipStream_t st = as_stream(stream);
+  {
+    const int r = linear_wres_f32(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+    if (r < 0) return r;
+    if (r > 0) return check_launch("linear (W-resident)");
+  }
   // split K across the 4 waves when there is more than one K-slice and the problem is small enough
   // to be latency bound (few row tiles); big problems read X once with all columns per wave.
   if (k > KT && n <= (int64_t(1) << 16)) {

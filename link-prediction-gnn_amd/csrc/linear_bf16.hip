@@ -186,6 +186,11 @@ LPG_EXPORT int lpg_linear_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w
                      reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(y) % 16 == 0;
   hipStream_t st = as_stream(stream);
+  {
+    const int r = linear_wres_bf16(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+    if (r < 0) return r;
+    if (r > 0) return check_launch("linear_bf16 (W-resident)");
+  }
   if (m <= 32) launch_bf16<1>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, vec_ok, st);
   else if (m <= 64) launch_bf16<2>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, vec_ok, st);
   else launch_bf16<4>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, vec_ok, st);

@@ -54,6 +54,13 @@ inline int grid_for(int64_t work_items, int block = kBlock, int64_t cap = 256 * 
     }                                                                        \
   } while (0)
 
+// linear_wres.hip: persistent W-resident kernels for big n; return 1 = launched, 0 = shape does not
+// qualify (the caller falls through to the tiled kernels), < 0 = error
+int linear_wres_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, int act, float* y,
+                    int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st);
+int linear_wres_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, int w_is_km, const float* bias, int act,
+                     uint16_t* y, int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st);
+
 __device__ __forceinline__ void flag_error(int32_t* err_flag, int32_t bit) {
   if (err_flag) atomicOr(err_flag, bit);
 }

@@ -221,7 +221,8 @@ def linear(x, weight, bias=None, w_is_km=False, out=None, act=None, n=None, ldx=
     _need_gpu(x, weight, bias)
     bf16 = x.dtype == torch.bfloat16                 # bf16 storage: v_mfma_f32_32x32x16_bf16, fp32 accumulate
     dt = torch.bfloat16 if bf16 else torch.float32
-    x = _c(x, dt)
+    if not (x.dim() == 2 and x.dtype == dt and x.stride(1) == 1 and x.stride(0) >= x.shape[1]):
+        x = _c(x, dt)                                # row-strided views (padded rows) are used in place
     weight = _c(weight, dt)
     bias = _c(bias, torch.float32)
     k = weight.shape[0] if w_is_km else weight.shape[1]

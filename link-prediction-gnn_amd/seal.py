@@ -205,11 +205,13 @@ def compact_tag_map(batch):
     return tag_map, T
 
 
-def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True):
+def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.float32):
     """SEAL/config/data.py:94-140 batched: block-diagonal A~ = A + I (CSR, values 1 / 2),
     D^-1 = 1/rowsum(A~) per vertex, X = [onehot(tag) || emb[node]].  Returns (CSRGraph, d_inv, X).
     fold_dinv (default): the CSR values are D^-1 A~, so graph_conv_stack needs no per-row scale in the
-    SpMM epilogue (a load at a row flush drains the gathers in flight); d_inv is still returned."""
+    SpMM epilogue (a load at a row flush drains the gathers in flight); d_inv is still returned.
+    X's rows are padded to a multiple of 16 bytes (a [total, T + dim] VIEW of a wider buffer), which is
+    what lets the first linear read them as 16-byte pieces; dtype=torch.bfloat16 stores X in bf16."""
     lib = _lib.load()
     dev = batch.n.device
     off = batch.node_off()
@@ -232,11 +234,16 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True):
     g.rows_prescaled = bool(fold_dinv)
     emb_dim = 0 if emb is None else emb.shape[1]
     emb = None if emb is None else _ops._c(emb, torch.float32)
-    x = torch.empty((total, tags_size + emb_dim), dtype=torch.float32, device=dev)
+    width = tags_size + emb_dim
+    x = torch.empty((total, -(-width // 8) * 8), dtype=torch.float32, device=dev)[:, :width]
     _lib.check(lib.lpg_seal_features_f32(P(batch.nodes), P(batch.n), P(off), P(batch.tags), P(tag_map),
                                          tag_map.numel(), tags_size, P(emb), emb_dim, batch.B, P(x), x.stride(0),
                                          P(_ops.err_flag(dev)), S()), "seal_features")
     _ops.maybe_check(dev, "seal feature index")
+    if dtype != torch.float32:
+        xs = torch.empty((total, -(-width // 8) * 8), dtype=dtype, device=dev)[:, :width]
+        xs.copy_(x)
+        x = xs
     return g, d_inv[:total], x
 
 

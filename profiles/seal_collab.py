@@ -27,10 +27,13 @@ emb = torch.randn((N, D), generator=gen, device=dev)
 k = 18
 
 
+BF16 = "--bf16" in sys.argv          # configs[2] says bf16: features, weights and activations stored in bf16
+
+
 def run():
     batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0)
     tag_map, T = seal.compact_tag_map(batch)
-    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb)
+    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb, dtype=torch.bfloat16 if BF16 else torch.float32)
     return batch, T, g, d_inv, x
 
 
@@ -42,14 +45,13 @@ hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, device=dev) * 0.1, "conv1d_kerne
       "weight_2": torch.randn(128, 2, device=dev), "bias_2": torch.zeros(2, device=dev)}
 
 
-BF16 = "--bf16" in sys.argv          # configs[2] says bf16: features, weights and activations stored in bf16
 gw16 = [w.bfloat16() for w in gw]
 
 
 def score():
     batch, T, g, d_inv, x = run()
     if BF16:
-        z, key = seal.graph_conv_stack(g, d_inv, x.bfloat16(), gw16)
+        z, key = seal.graph_conv_stack(g, d_inv, x, gw16)
         z, key = z.float(), key.float()
     else:
         z, key = seal.graph_conv_stack(g, d_inv, x, gw)

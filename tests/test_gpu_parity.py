@@ -762,6 +762,59 @@ def test_linear_bf16_mfma(dev, n, k, m, km):
     assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + TOL * mag + 1e-30)
 
 
+@pytest.mark.parametrize("variant", ["auto", "1", "2"])
+@pytest.mark.parametrize("dtype,n,k,m,ldx,km,act,bias", [
+    ("f32", 20011, 128, 128, 128, False, None, True),       # MFMA-bound shape, ragged last tile
+    ("f32", 16385, 32, 32, 32, True, "tanh", False),
+    ("f32", 40000, 64, 64, 64, False, "relu", True),
+    ("f32", 20011, 100, 20, 100, False, "relu", True),      # k padded 100 -> 128 in LDS, m < one column tile
+    ("f32", 20011, 30, 7, 32, True, None, True),            # ragged k inside a 16-byte piece, padded rows
+    ("f32", 17000, 128, 200, 128, False, None, True),       # two column blocks
+    ("bf16", 20011, 128, 128, 128, False, None, True),
+    ("bf16", 20011, 256, 128, 256, False, "relu", False),
+    ("bf16", 20011, 134, 32, 136, True, "tanh", False),     # SEAL's first layer: [onehot(6) || 128], padded rows
+    ("bf16", 16385, 32, 32, 32, True, None, True),
+    ("bf16", 20011, 100, 20, 104, False, "relu", True),
+])
+def test_linear_persistent_w_resident(dev, monkeypatch, variant, dtype, n, k, m, ldx, km, act, bias):
+    """n >= 16384 takes the persistent W-resident kernels (csrc/linear_wres.hip); both variants and the
+    shape-based choice against an fp64 matmul of the same (rounded) inputs; NaN in the row padding must
+    never reach the result."""
+    from lpgnn_amd import ops
+    if variant == "auto":
+        monkeypatch.delenv("LPG_LINEAR_WRES", raising=False)
+    else:
+        monkeypatch.setenv("LPG_LINEAR_WRES", variant)
+    rng = np.random.default_rng(n + k + m)
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    xb = torch.from_numpy(rng.standard_normal((n, ldx)).astype(np.float32)).to(dev).to(dt)
+    if ldx > k:
+        xb[:, k:] = float("nan")
+    xt = xb[:, :k]
+    wt = torch.from_numpy(rng.standard_normal((k, m) if km else (m, k)).astype(np.float32)).to(dev).to(dt)
+    b = rng.standard_normal(m).astype(np.float32) if bias else None
+    x64, w64 = _np(xt.float()).astype(np.float64), _np(wt.float()).astype(np.float64)
+    if not km:
+        w64 = w64.T
+    want = x64 @ w64 + (b if bias else 0.0)
+    mag = np.abs(x64) @ np.abs(w64) + (np.abs(b) if bias else 0.0)
+    got = ops.linear(xt, wt, None if b is None else torch.from_numpy(b).to(dev), w_is_km=km, act=act)
+    assert got.shape == (n, m) and got.dtype == dt
+    got = _np(got.float()).astype(np.float64)
+    if act == "relu":
+        want = np.maximum(want, 0)
+    elif act == "tanh":
+        want = np.tanh(want)
+    store = 2.0 ** -8 * np.abs(want) if dtype == "bf16" else 0.0
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - want) <= store + TOL * (mag + 1.0) + 1e-30)
+    # an output that is a column slice of a wider buffer: nothing outside [n, m] may be written
+    wide = torch.full((n, m + 8), 7.0, dtype=dt, device=dev)
+    ops.linear(xt, wt, None if b is None else torch.from_numpy(b).to(dev), w_is_km=km, act=act, out=wide[:, :m])
+    assert torch.equal(wide[:, m:], torch.full((n, 8), 7.0, dtype=dt, device=dev))
+    assert np.array_equal(_np(wide[:, :m].float()).astype(np.float64), got)
+
+
 def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
     """configs[2] numerics: the SEAL graph-conv stack with X, weights and activations stored in
     bf16 (fp32 accumulate everywhere) stays within bf16 rounding of the fp32 stack."""
