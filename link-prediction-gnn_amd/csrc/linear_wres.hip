@@ -55,6 +55,25 @@ __device__ __forceinline__ void mfma_group(const uint4& a, const uint4& b, f32x1
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
 }
 
+// one fragment group for all NT column tiles.  fp32: the four k-steps are the OUTER loop so that consecutive
+// MFMAs write different accumulators (a dependent chain on one accumulator cannot issue back to back).
+template <int NT>
+__device__ __forceinline__ void mfma_groups(const uint4& a, const uint4 (&b)[NT], f32x16 (&acc)[NT], float*) {
+  const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint32_t bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[i]), __uint_as_float(bv), acc[t], 0, 0, 0);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mfma_groups(const uint4& a, const uint4 (&b)[NT], f32x16 (&acc)[NT], uint16_t*) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mfma_group(a, b[t], acc[t], static_cast<uint16_t*>(nullptr));
+}
+
 // zero the elements >= keep of a 16-byte piece (keep in [0, EPB])
 __device__ __forceinline__ uint4 keep_first(uint4 v, int keep, float*) {
   v.x = keep > 0 ? v.x : 0u; v.y = keep > 1 ? v.y : 0u; v.z = keep > 2 ? v.z : 0u; v.w = keep > 3 ? v.w : 0u;
@@ -272,11 +291,10 @@ __global__ __launch_bounds__(kBlock, 2) void linear_wres2_kernel(
         a = keep_first(a, k - ko, static_cast<T*>(nullptr));
       }
       xr[g] = *reinterpret_cast<const uint4*>(rp + (ko < k ? ko : 0));   // refill in place for the next tile
+      uint4 b[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const uint4 b = *reinterpret_cast<const uint4*>(bp + t * 32 * LD + g * GK);
-        mfma_group(a, b, acc[t], static_cast<T*>(nullptr));
-      }
+      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const uint4*>(bp + t * 32 * LD + g * GK);
+      mfma_groups<NT>(a, b, acc, static_cast<T*>(nullptr));
       // without this the scheduler hoists every W fragment read of the unrolled loop to the top
       // (PG * NT * 4 registers) and spills the accumulators
       if (g % 2 == 1) __builtin_amdgcn_sched_barrier(0);
@@ -377,7 +395,7 @@ int dispatch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float*
     // measured on MI355X (profiles/r01/linear_ab.log): the MFMA-bound fp32 shapes and k > 128 bf16 want the
     // staging-free variant 2; the HBM-bound rest wants the coalesced variant 1; bf16 [k = 128] -> [m <= 32] is
     // the one shape where the tiled kernel is still ahead (0.28 vs 0.32 ms at n = 5 M)
-    if (sizeof(T) == 4) variant = (nt == 4 || (nt == 2 && pg >= 8)) ? 2 : 1;
+    if (sizeof(T) == 4) variant = nt == 4 ? 2 : 1;
     else variant = pg == 16 ? 2 : 1;
     if (sizeof(T) == 2 && nt == 1 && pg == 8 && k % 8 == 0 && m % 8 == 0 && ldy % 8 == 0) return 0;
   }
