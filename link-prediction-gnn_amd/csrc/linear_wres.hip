@@ -341,7 +341,7 @@ int launch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float* b
   const int64_t n_tiles = ceil_div(n, 32);
   const unsigned gy = static_cast<unsigned>(ceil_div(m, NT * 32));
   static int per_cu[2] = {0, 0};                    // per instantiation; the occupancy query is slow
-  if (variant == 2) {
+  if (variant == 2 || PG == 20) {                   // PG = 20 (fp32, 128 < k <= 160) exists as variant 2 only
     auto kern = linear_wres2_kernel<T, NT, PG, ACT>;
     constexpr size_t lds = static_cast<size_t>(NT) * 32 * LD * sizeof(T);
     if (!per_cu[1]) per_cu[1] = blocks_per_cu(kern, lds);
@@ -349,7 +349,7 @@ int launch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float* b
     const int64_t gx = std::min<int64_t>(static_cast<int64_t>(cu_count()) * per_cu[1], ceil_div(n_tiles, kBlock / 64));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx), gy), dim3(kBlock), lds, st, x, ldx, w, w_is_km, bias, y,
                        ldy, n, k, m, n_tiles);
-  } else {
+  } else if constexpr (PG != 20) {
     auto kern = linear_wres_kernel<T, NT, PG, ACT>;
     constexpr size_t lds = (static_cast<size_t>(NT) * 32 * LD + 4 * 32 * static_cast<size_t>(LD > LDO ? LD : LDO)) * sizeof(T);
     if (!per_cu[0]) per_cu[0] = blocks_per_cu(kern, lds);
@@ -383,14 +383,15 @@ int dispatch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float*
   constexpr int EPB = Elt<T>::EPB, GK = Elt<T>::GK;
   const char* env = getenv("LPG_LINEAR_WRES");            // tuning / A-B hook, re-read per call: 0 off, 1 / 2 variant
   int variant = env ? atoi(env) : -1;
-  if (variant == 0 || n < 16384 || k > 16 * GK || m > 65535 * 32) return 0;
+  const int nt = m <= 32 ? 1 : (m <= 64 ? 2 : 4);
+  const bool wide = sizeof(T) == 4 && k > 16 * GK && k <= 20 * GK && nt <= 2;   // SEAL's [onehot || 128-d] rows
+  if (variant == 0 || n < 16384 || (k > 16 * GK && !wide) || m > 65535 * 32) return 0;
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   // X is read as whole 16-byte pieces of a row: rows must start 16-byte aligned and the last piece of a
   // row must lie inside the allocation (elements >= k are masked in registers, never used)
   if (ldx % EPB != 0 || !al16(x)) return 0;
   if (k % EPB != 0 && align_up(k, EPB) > ldx) return 0;    // overlapping row windows (ldx < k) with a ragged k
-  const int pg = k <= 4 * GK ? 4 : (k <= 8 * GK ? 8 : 16);
-  const int nt = m <= 32 ? 1 : (m <= 64 ? 2 : 4);
+  const int pg = k <= 4 * GK ? 4 : (k <= 8 * GK ? 8 : (k <= 16 * GK ? 16 : 20));
   if (variant < 0) {
     // measured on MI355X (profiles/r01/linear_ab.log): the MFMA-bound fp32 shapes and k > 128 bf16 want the
     // staging-free variant 2; the HBM-bound rest wants the coalesced variant 1; bf16 [k = 128] -> [m <= 32] is
@@ -403,7 +404,12 @@ int dispatch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float*
   const int ki = static_cast<int>(k), mi = static_cast<int>(m);
   if (pg == 4) return launch_nt<T, 4>(nt, x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, y_vec, variant, st);
   if (pg == 8) return launch_nt<T, 8>(nt, x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, y_vec, variant, st);
-  return launch_nt<T, 16>(nt, x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, y_vec, variant, st);
+  if (pg == 16) return launch_nt<T, 16>(nt, x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, y_vec, variant, st);
+  if constexpr (sizeof(T) == 4) {
+    if (nt == 1) return launch_act<T, 1, 20>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, y_vec, 2, st);
+    return launch_act<T, 2, 20>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, y_vec, 2, st);
+  }
+  return 0;
 }
 }  // namespace
 

@@ -107,8 +107,12 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
   __shared__ uint32_t adj[MAXN][WORDS];
   __shared__ int dist0[MAXN], dist1[MAXN];
   __shared__ uint32_t vis[WORDS], fr[WORDS], nx[WORDS];
-  __shared__ int s_n, s_capped;
+  __shared__ int s_n, s_capped, s_cnt[2], s_nbig;
   __shared__ ListPlan s_list[2];
+  __shared__ int64_t rbase[MAXN];                  // per subgraph vertex: its neighbour list in the big graph
+  __shared__ int rdeg[MAXN];
+  __shared__ int big[MAXN];                        // rows whose list is searched instead of streamed
+  __shared__ int pre[MAXN + 2];                    // exclusive prefix of the streamed rows' list lengths
   const int t = threadIdx.x;
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
@@ -139,22 +143,27 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
       __syncthreads();
     } else {
       // ---- node set: {u, v} U N(u) U N(v) with the reference's cap rule (subgraph.py:118-135)
+      // The reference visits the two targets in a SHUFFLED order (:122); the truncation branch
+      // (:124-130) fires when len(sub) + len(neighbours) >= max_neighbors at a visit.  `capped` is
+      // reported when it would fire in EITHER order, so an uncapped result is order- and RNG-free.
+      // Everything below is block-uniform; the two neighbour counts are taken by all threads at once
+      // (one thread walking up to 2 x 100 list entries was ~10 us of dependent loads per pair).
+      const int size0 = (u == v) ? 1 : 2;
+      const int64_t bu = rowptr[u], du = rowptr[u + 1] - bu;
+      const int64_t bv = rowptr[v], dv = rowptr[v + 1] - bv;
+      if (t < 2) s_cnt[t] = 0;
+      __syncthreads();
+      if (hop >= 1) {                                  // neighbours other than the targets, lists shorter than the cap
+        if (size0 + du < max_nb && t < du) { const int32_t x = col[bu + t]; if (x != u && x != v) atomicAdd(&s_cnt[0], 1); }
+        if (size0 + dv < max_nb && t < dv) { const int32_t x = col[bv + t]; if (x != u && x != v) atomicAdd(&s_cnt[1], 1); }
+      }
+      __syncthreads();
       if (t == 0) {
-        // The reference visits the two targets in a SHUFFLED order (:122); the truncation branch
-        // (:124-130) fires when len(sub) + len(neighbours) >= max_neighbors at a visit.  `capped` is
-        // reported when it would fire in EITHER order, so an uncapped result is order- and RNG-free.
-        const int size0 = (u == v) ? 1 : 2;
-        const int64_t bu = rowptr[u], du = rowptr[u + 1] - bu;
-        const int64_t bv = rowptr[v], dv = rowptr[v + 1] - bv;
-        int cap = 0, eu = 0, ev = 0;
+        const int eu = s_cnt[0], ev = s_cnt[1];
+        int cap = 0;
         if (hop >= 1) {
-          if (size0 + du >= max_nb || size0 + dv >= max_nb) {
-            cap = 1;
-          } else {
-            for (int64_t k = 0; k < du; ++k) { const int32_t x = col[bu + k]; eu += (x != u && x != v); }
-            for (int64_t k = 0; k < dv; ++k) { const int32_t x = col[bv + k]; ev += (x != u && x != v); }
-            if (size0 + eu + dv >= max_nb || size0 + ev + du >= max_nb) cap = 1;
-          }
+          if (size0 + du >= max_nb || size0 + dv >= max_nb) cap = 1;
+          else if (size0 + eu + dv >= max_nb || size0 + ev + du >= max_nb) cap = 1;
         }
         s_capped = cap;
         // plan the two neighbour lists: (node, count, affine permutation a*i+b mod deg)
@@ -175,10 +184,7 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
             int size = size0;
             if (size + d1 < max_nb) {
               s_list[0] = ListPlan{first, static_cast<int>(d1), d1, 1, 0};
-              const int64_t b1 = swap ? bv : bu;
-              int e1 = 0;
-              for (int64_t k = 0; k < d1; ++k) { const int32_t x = col[b1 + k]; e1 += (x != u && x != v); }
-              size += e1;
+              size += swap ? ev : eu;                  // counted above: this list is shorter than the cap
               if (u != v) {
                 if (size + d2 < max_nb)
                   s_list[1] = ListPlan{second, static_cast<int>(d2), d2, 1, 0};
@@ -246,12 +252,83 @@ __global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
     const int was_capped = replay ? 0 : s_capped;
 
     // ---- induced adjacency: bit (i, j) = A[nodes[i], nodes[j]], target entries cleared (:136-137)
-    for (int p = t; p < n * n; p += kSealBlock) {
-      const int i = p / n, j = p - i * n;
-      const int32_t a = nodes[i];
+    // Row i's neighbour list is STREAMED (16 lanes per row, coalesced) and each neighbour looked up among
+    // the subgraph's vertices in LDS (nodes[2..n) is sorted ascending by construction).  Only rows with a
+    // long list (hubs: thousands of neighbours) are not streamed: symmetry fills them from the other side, and
+    // only hub x hub entries are binary-searched.  The first version searched every (i, j): 10 K dependent-load
+    // chains for a capped subgraph.
+    if (t == 0) s_nbig = 0;
+    __syncthreads();
+    if (t < n) {
+      const int32_t a = nodes[t];
       const int64_t ba = rowptr[a];
       const int da = static_cast<int>(rowptr[a + 1] - ba);
-      if (row_has(col + ba, da, nodes[j]) && !((i == 0 && j == 1) || (i == 1 && j == 0)))
+      rbase[t] = ba;
+      rdeg[t] = da;
+      if (replay || da > 256) big[atomicAdd(&s_nbig, 1)] = t;     // replayed node lists need not be sorted
+    }
+    __syncthreads();
+    if (!replay) {
+      // exclusive prefix of the streamed rows' list lengths (wave scan + the first wave's total), then the
+      // (row, k) items are dealt round-robin to the threads: no thread walks a row alone, and the 4 loads of a
+      // round are independent (per-row loops paid one global round trip per row: 20 us for a 100-vertex subgraph)
+      const int mylen = (t < n && rdeg[t] <= 256) ? rdeg[t] : 0;
+      int inc = mylen;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if ((t & 63) >= o) inc += up;
+      }
+      if (t == 63) pre[MAXN] = inc;                    // total of wave 0
+      __syncthreads();
+      const int excl = inc - mylen + (t >= 64 ? pre[MAXN] : 0);
+      pre[t] = excl;
+      if (t == kSealBlock - 1) pre[MAXN + 1] = excl + mylen;
+      __syncthreads();
+      const int total = pre[MAXN + 1];
+      for (int p0 = t; p0 < total; p0 += 4 * kSealBlock) {
+        int row[4];
+        int32_t x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = p0 + q * kSealBlock;
+          int lo = 0, hi = n;                            // last row i with pre[i] <= p (empty rows share a prefix value)
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= p) lo = mid; else hi = mid;
+          }
+          row[q] = lo;
+          x[q] = p < total ? col[rbase[lo] + (p - pre[lo])] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = row[q];
+          const int32_t xv = x[q];
+          if (xv < 0) continue;
+          // the adjacency is symmetric (ABI contract): every hit also sets its mirror entry, which is how the
+          // rows of hubs get filled without ever touching their lists
+          const uint32_t ibit = 1u << (i & 31);
+          if (xv == u && i != 1) { atomicOr(&adj[i][0], 1u); atomicOr(&adj[0][i >> 5], ibit); }   // (1,0) is a target entry
+          if (xv == v && i != 0) { atomicOr(&adj[i][0], 2u); atomicOr(&adj[1][i >> 5], ibit); }   // (0,1) likewise
+          if (xv != u && xv != v) {
+            int lo = 2, hi = n;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (nodes[mid] < xv) lo = mid + 1; else hi = mid;
+            }
+            if (lo < n && nodes[lo] == xv) {
+              atomicOr(&adj[i][lo >> 5], 1u << (lo & 31));
+              atomicOr(&adj[lo][i >> 5], ibit);
+            }
+          }
+        }
+      }
+    }
+    // what is left: hub x hub entries (neither list was streamed), or everything when a node list is replayed
+    const int nbig = s_nbig, ncol = replay ? n : nbig;
+    for (int p = t; p < nbig * ncol; p += kSealBlock) {
+      const int i = big[p / ncol], j = replay ? p % ncol : big[p % ncol];
+      if (row_has(col + rbase[i], rdeg[i], nodes[j]) && !((i == 0 && j == 1) || (i == 1 && j == 0)))
         atomicOr(&adj[i][j >> 5], 1u << (j & 31));
     }
     __syncthreads();
@@ -359,30 +436,44 @@ __global__ __launch_bounds__(kBlock) void seal_fill_kernel(const int64_t* __rest
   }
 }
 
+// One workgroup walks whole subgraphs (grid-stride over b), a wave takes one vertex row at a time and its
+// lanes the columns: the one-hot part is computed, the embedding part is a coalesced copy of emb[node]
+// (512 B for dim 128).  No per-element division or offset search (the first version spent 2.9 ms on 0.8 GB).
 __global__ __launch_bounds__(kBlock) void seal_features_kernel(const int32_t* __restrict__ nodes,
                                                                const int64_t* __restrict__ node_off,
                                                                const int32_t* __restrict__ tags,
                                                                const int32_t* __restrict__ tag_map, int64_t tag_map_len,
                                                                int64_t T, const float* __restrict__ emb, int64_t emb_dim,
-                                                               int64_t B, int64_t total, float* __restrict__ x,
-                                                               int64_t ldx, int32_t* err_flag) {
-  const int64_t width = T + emb_dim;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total * width; q += stride) {
-    const int64_t g = q / width, c = q - g * width;
-    const int64_t b = graph_of(node_off, B, g);
-    const int i = static_cast<int>(g - node_off[b]);
-    float v;
-    if (c < T) {
+                                                               int64_t B, float* __restrict__ x, int64_t ldx,
+                                                               int32_t* err_flag) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int width = static_cast<int>(T + emb_dim);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const int64_t base = node_off[b];
+    int n = static_cast<int>(node_off[b + 1] - base);
+    if (n > MAXN) n = MAXN;
+    for (int i = wave; i < n; i += kBlock / 64) {
       int32_t tg = tags[b * MAXN + i];
       if (tag_map) {
-        if (tg >= 0 && tg < tag_map_len) tg = tag_map[tg]; else { flag_error(err_flag, LPG_F_INDEX_RANGE); tg = -1; }
+        if (tg >= 0 && tg < tag_map_len) tg = tag_map[tg];
+        else { if (lane == 0) flag_error(err_flag, LPG_F_INDEX_RANGE); tg = -1; }
       }
-      v = (tg == c) ? 1.f : 0.f;
-    } else {
-      v = emb[static_cast<int64_t>(nodes[b * MAXN + i]) * emb_dim + (c - T)];
+      const float* erow = emb ? emb + static_cast<int64_t>(nodes[b * MAXN + i]) * emb_dim - T : nullptr;
+      float* xrow = x + (base + i) * ldx;
+      for (int c0 = 0; c0 < width; c0 += 256) {      // 4 columns in flight per lane
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + u * 64 + lane;
+          v[u] = (c >= T && c < width) ? erow[c] : ((tg == c) ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + u * 64 + lane;
+          if (c < width) xrow[c] = v[u];
+        }
+      }
     }
-    x[g * ldx + c] = v;
   }
 }
 // ---- SortPooling: one workgroup per subgraph; rank sort of <= 128 keys in LDS -------------------
@@ -492,13 +583,10 @@ LPG_EXPORT int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_node
   (void)n_nodes;
   if (B == 0 || T + emb_dim == 0) return LPG_OK;
   LPG_REQUIRE(nodes && node_off && tags && x && (emb_dim == 0 || emb), "seal_features: null pointer");
-  hipStream_t st = as_stream(stream);
-  int64_t total = 0;
-  LPG_HIP(hipMemcpyAsync(&total, node_off + B, 8, hipMemcpyDeviceToHost, st));
-  LPG_HIP(hipStreamSynchronize(st));
-  if (total > 0)
-    hipLaunchKernelGGL(seal_features_kernel, dim3(grid_for(total * (T + emb_dim))), dim3(kBlock), 0, st, nodes, node_off, tags,
-                       tag_map, tag_map_len, T, emb, emb_dim, B, total, x, ldx, err_flag);
+  LPG_REQUIRE(T + emb_dim < (int64_t(1) << 30), "seal_features: row too wide");
+  const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
+  hipLaunchKernelGGL(seal_features_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), nodes, node_off, tags, tag_map,
+                     tag_map_len, T, emb, emb_dim, B, x, ldx, err_flag);
   return check_launch("seal_features");
 }
 

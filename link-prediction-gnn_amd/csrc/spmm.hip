@@ -58,7 +58,10 @@ inline int chunk_for(int64_t e_cap) {
   const int forced = tune().chunk;
   if (forced) return forced;
   int c = 16;
-  while (c < kDefaultChunk && static_cast<int64_t>(c) * 2 * 4096 <= e_cap) c *= 2;
+  // enough chunks to put >= 16 waves on every SIMD even when a wave covers 64 chunks (d <= 4): the big
+  // HBM-bound graphs end at 512 (|E| = 100 M: 8.55 ms vs 8.67 at 256, 8.89 at 128), a batch of SEAL
+  // subgraphs (8.5 M edges, d = 32 and d = 1) at 64 (4-layer stack 2.35 ms at 512 -> 1.6 ms)
+  while (c < kDefaultChunk && static_cast<int64_t>(c) * (int64_t(1) << 18) <= e_cap) c *= 2;
   return c;
 }
 
@@ -71,7 +74,7 @@ struct SpmmArgs {
   const int32_t* empty_rows;
   const void* x;
   void* y;
-  int64_t ldx, ldy, N, d;
+  int64_t ldx, ldy, N, d, n_cols;
   const float* row_scale;
   const float* bias;
   int act;
@@ -353,6 +356,140 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
   if (open_right && lane_on) carry_store<VEC>(carry0 + ((first_seg && open_left) ? 0 : a.dpad), acc);
 }
 
+// ---- narrow features (d = 1, 2, 4, 8, 16): lanes are EDGES, not feature columns ---------------------------
+// With d <= 4 the main kernel's "G lanes per chunk" degenerates to one lane walking a chunk alone (64 chunks
+// per wave, every index load 64 cache lines wide, a row flush on almost every step): 0.5 ms for the 8.5 M-edge
+// SEAL batch at d = 1.  Here a wave owns one chunk and takes 64 consecutive edges per step -- col / rowid / val
+// loads are fully coalesced -- multiplies, and reduces rows with a segmented inclusive scan across the lanes
+// (rows are contiguous in CSR order, so "same row as the lane o places back" is the segment test).  The lane
+// holding a row's last edge stores it; a row still open at the end of a 64-edge step continues in `run`.
+// Chunk borders use the same carry slots and the same fix-up kernel as the main kernel.  The order of the
+// additions inside a row is a fixed tree, so results are bitwise reproducible, but it is NOT the left-to-right
+// order of oracle/spmm_ref.c (the bit-exact-vs-C test covers the main kernel; this path is tolerance-tested).
+template <typename T> __device__ __forceinline__ float elt_to_f32(T v);
+template <> __device__ __forceinline__ float elt_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float elt_to_f32<uint16_t>(uint16_t v) { return bf16_to_f32(v); }
+template <typename T> __device__ __forceinline__ T f32_to_elt(float v);
+template <> __device__ __forceinline__ float f32_to_elt<float>(float v) { return v; }
+template <> __device__ __forceinline__ uint16_t f32_to_elt<uint16_t>(float v) { return f32_to_bf16(v); }
+
+// DV consecutive elements of a row; VIO: 16-byte pieces (the caller checked alignment and DV % pieces == 0)
+template <typename T, int DV, bool VIO>
+__device__ __forceinline__ void load_elts(const T* p, float (&v)[DV]) {
+  if constexpr (VIO) {
+    constexpr int PV = 16 / sizeof(T);
+#pragma unroll
+    for (int i = 0; i < DV; i += PV) {
+      float t[PV];
+      Piece<T, PV>::widen(Piece<T, PV>::load(p + i), t);
+#pragma unroll
+      for (int k = 0; k < PV; ++k) v[i + k] = t[k];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < DV; ++i) v[i] = elt_to_f32<T>(p[i]);
+  }
+}
+template <typename T, int DV, bool VIO>
+__device__ __forceinline__ void store_elts(T* p, const float (&v)[DV]) {
+  if constexpr (VIO) {
+    constexpr int PV = 16 / sizeof(T);
+#pragma unroll
+    for (int i = 0; i < DV; i += PV) {
+      float t[PV];
+#pragma unroll
+      for (int k = 0; k < PV; ++k) t[k] = v[i + k];
+      Piece<T, PV>::store(p + i, t);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < DV; ++i) p[i] = f32_to_elt<T>(v[i]);
+  }
+}
+
+template <typename T, int DV, bool WEIGHTED, bool VIO>
+__global__ __launch_bounds__(kBlock) void spmm_edge_kernel(const SpmmArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int kChunk = a.chunk;
+  const int64_t E = a.rowptr[a.N];
+  const int64_t start = chunk * kChunk;
+  if (start >= E) return;                           // wave-uniform
+  const int n_e = E - start > kChunk ? kChunk : static_cast<int>(E - start);
+  const int r_start = a.rowid[start];
+  const bool open_left = start > 0 && a.rowid[start - 1] == r_start;
+  const int64_t last = start + n_e - 1;
+  const bool open_right = last + 1 < E && a.rowid[last] == a.rowid[last + 1];
+  float* carry0 = a.carry + (2 * chunk) * a.dpad;
+  const T* xb = static_cast<const T*>(a.x);
+  T* yb = static_cast<T*>(a.y);
+  float run[DV];                                    // wave-uniform: partial sum of the row open at the step start
+#pragma unroll
+  for (int i = 0; i < DV; ++i) run[i] = 0.f;
+  int run_row = -1;
+
+  for (int base = 0; base < n_e; base += 64) {
+    const bool in = base + lane < n_e;
+    const int64_t e = start + base + lane;
+    const int c = in ? a.col[e] : 0;
+    const int r = in ? a.rowid[e] : -1;
+    const int rn = (in && e + 1 < E) ? a.rowid[e + 1] : -2;
+    float w = 1.f;
+    if constexpr (WEIGHTED) w = in ? a.val[e] : 0.f;
+    float v[DV];
+    load_elts<T, DV, VIO>(xb + static_cast<int64_t>(c) * a.ldx, v);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) v[i] = in ? (WEIGHTED ? w * v[i] : v[i]) : 0.f;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {              // segmented inclusive scan, lane order = edge order
+      const int rr = __shfl_up(r, o, 64);
+      const bool same = lane >= o && rr == r;
+#pragma unroll
+      for (int i = 0; i < DV; ++i) {
+        const float t = __shfl_up(v[i], o, 64);
+        if (same) v[i] += t;
+      }
+    }
+    if (in && r != rn) {                            // this lane holds the row's last edge
+      float tot[DV];
+#pragma unroll
+      for (int i = 0; i < DV; ++i) tot[i] = r == run_row ? run[i] + v[i] : v[i];
+      if (open_left && r == r_start) {              // tail of a row begun in an earlier chunk: the fix-up finishes it
+#pragma unroll
+        for (int i = 0; i < DV; ++i) carry0[i] = tot[i];
+      } else {
+        const float rs = a.row_scale ? a.row_scale[r] : 1.f;
+        float o[DV];
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+          o[i] = tot[i] * rs;
+          if (a.bias) o[i] += a.bias[i];
+          o[i] = apply_act(o[i], a.act);
+        }
+        store_elts<T, DV, VIO>(yb + static_cast<int64_t>(r) * a.ldy, o);
+      }
+    }
+    // the row open at the end of this step (if any) continues
+    const int L = n_e - base > 64 ? 63 : n_e - base - 1;
+    const int rL = __shfl(r, L, 64), rnL = __shfl(rn, L, 64);
+    if (rL != rnL) {
+      run_row = -1;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DV; ++i) {
+        const float vL = __shfl(v[i], L, 64);
+        run[i] = rL == run_row ? run[i] + vL : vL;
+      }
+      run_row = rL;
+    }
+  }
+  if (open_right && lane == 0) {
+    float* slot = carry0 + ((open_left && run_row == r_start) ? 0 : a.dpad);   // one row through the whole chunk: slot 0
+#pragma unroll
+    for (int i = 0; i < DV; ++i) slot[i] = run[i];
+  }
+}
+
 // ---- fix-up: finish the rows that straddle chunk borders --------------------------------------
 template <typename T, int VEC, int G>
 __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
@@ -427,7 +564,11 @@ int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
   int lds = tn.lds;
   if (lds < 0) {
     lds = 0;
-    if (e_cap >= (int64_t(1) << 20))
+    // ... only where the gathers actually go to HBM: X must be much larger than the 256 MB Infinity Cache.
+    // A block-diagonal batch of SEAL subgraphs (X = 187 MB, every gather lands in its own subgraph's few
+    // KB) is L2-latency bound instead and wants every wave it can get: 3.4 -> 1.9 ms for the 4-layer stack.
+    const int64_t x_bytes = a.n_cols * a.ldx * static_cast<int64_t>(sizeof(T));
+    if (e_cap >= (int64_t(1) << 20) && x_bytes >= (int64_t(384) << 20))
       lds = (sizeof(T) == 4 && G * VEC * sizeof(T) >= 512) ? 90000 : 65536;
   }
   const int64_t n_waves = ceil_div(n_chunks, GPW);
@@ -493,14 +634,41 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
   a.n_empty = reinterpret_cast<const int32_t*>(p);
   a.rowid = reinterpret_cast<const int32_t*>(p + 256);
   a.empty_rows = reinterpret_cast<const int32_t*>(p + 256 + align_up((e_cap + 1) * 4, 256));
-  a.x = x; a.y = y; a.ldx = ldx; a.ldy = ldy; a.N = N; a.d = d;
+  a.x = x; a.y = y; a.ldx = ldx; a.ldy = ldy; a.N = N; a.d = d; a.n_cols = n_cols;
   a.row_scale = row_scale; a.bias = bias; a.act = act;
   a.carry = static_cast<float*>(workspace);
   a.dpad = align_up(d, 4);
   a.chunk = chunk_for(e_cap);
   a.off32 = (n_cols > 0 && static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * sizeof(T) <= (uint64_t(1) << 32)) ? 1 : 0;
   if (!tune().off32) a.off32 = 0;
-  if (e_cap > 0) {
+  // d <= 16 in a power of two: the edge-parallel kernel (lanes = edges); wider rows: lanes = feature columns
+  const bool narrow = (d == 1 || d == 2 || d == 4 || d == 8 || d == 16) && tune().mode == 0 && !getenv("LPG_SPMM_NO_EDGE");
+  if (e_cap > 0 && narrow) {
+    const int64_t n_chunks = ceil_div(e_cap, a.chunk);
+    const int64_t gx = ceil_div(n_chunks, kBlock / kWave);
+    LPG_REQUIRE(gx < (int64_t(1) << 31), "csr_spmm: grid too large");
+    constexpr int PV = 16 / sizeof(T);
+    const bool vio = d % PV == 0 && ldx % PV == 0 && ldy % PV == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(y) % 16 == 0;
+    const dim3 eg(static_cast<unsigned>(gx)), blk(kBlock);
+#define LPG_EDGE_IO(DVV, VIOV)                                                                      \
+  do {                                                                                              \
+    if (a.val) hipLaunchKernelGGL((spmm_edge_kernel<T, DVV, true, VIOV>), eg, blk, 0, st, a);       \
+    else hipLaunchKernelGGL((spmm_edge_kernel<T, DVV, false, VIOV>), eg, blk, 0, st, a);            \
+  } while (0)
+#define LPG_EDGE(DVV)                                                                               \
+  do {                                                                                              \
+    if constexpr (DVV % PV == 0) { if (vio) LPG_EDGE_IO(DVV, true); else LPG_EDGE_IO(DVV, false); } \
+    else LPG_EDGE_IO(DVV, false);                                                                   \
+    constexpr int FG = DVV;                                                                         \
+    const int64_t fw = ceil_div(n_chunks, kWave / FG);                                              \
+    hipLaunchKernelGGL((spmm_fixup_kernel<T, 1, FG>), dim3(static_cast<unsigned>(ceil_div(fw, kBlock / kWave))), blk, 0, st, a); \
+  } while (0)
+    if (d == 1) LPG_EDGE(1); else if (d == 2) LPG_EDGE(2); else if (d == 4) LPG_EDGE(4);
+    else if (d == 8) LPG_EDGE(8); else LPG_EDGE(16);
+#undef LPG_EDGE
+#undef LPG_EDGE_IO
+  } else if (e_cap > 0) {
     const bool wide = d % WIDE == 0 && ldx % WIDE == 0 && ldy % WIDE == 0 &&
                       reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
     const int rc = wide ? launch_vec<T, WIDE>(a, e_cap, st) : launch_vec<T, 1>(a, e_cap, st);

@@ -250,13 +250,17 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.
 def graph_conv_stack(g, d_inv, x, weights):
     """SEAL/model/gnn.py:46-63: Z_l = tanh(D^-1 (A~ (Z_{l-1} W_l))), l = 1..4.
     Returns (concat(Z1, Z2, Z3) [total, 96], Z4[:, 0] -- the SortPooling key, :82)."""
-    z, zs = x, []
-    for w in weights:                                             # x bf16 => the whole stack runs in bf16 storage
+    widths = [w.shape[1] for w in weights]
+    cat = torch.empty((x.shape[0], sum(widths[:-1])), dtype=x.dtype, device=x.device)   # concat(Z1..Z3), written in place
+    z, c0 = x, 0
+    for li, w in enumerate(weights):                              # x bf16 => the whole stack runs in bf16 storage
         h = _ops.linear(z, w, w_is_km=True)                       # K5 on the matrix cores (fp32 or bf16 MFMA)
         rs = None if getattr(g, "rows_prescaled", False) else d_inv
-        z = g.spmm(h, row_scale=rs, act="tanh")                   # K10: one fused kernel per layer
-        zs.append(z)
-    return torch.cat(zs[:3], dim=1), zs[3][:, 0]
+        last = li == len(weights) - 1
+        out = None if last else cat[:, c0:c0 + widths[li]]        # each layer lands in its column slice: no torch.cat
+        z = g.spmm(h, row_scale=rs, act="tanh", out=out)          # K10: one fused kernel per layer
+        c0 += widths[li]
+    return cat, z[:, 0]
 
 
 def sortpool(z, key, node_off, k):

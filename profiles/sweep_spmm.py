@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-KEYS = ["LPG_SPMM_CHUNK", "LPG_SPMM_U", "LPG_SPMM_MODE", "LPG_SPMM_LDS", "LPG_SPMM_PIPE", "LPG_SPMM_BLOCK", "LPG_SPMM_OFF32"]
+KEYS = ["LPG_SPMM_CHUNK", "LPG_SPMM_U", "LPG_SPMM_MODE", "LPG_SPMM_LDS", "LPG_SPMM_PIPE", "LPG_SPMM_BLOCK", "LPG_SPMM_OFF32", "LPG_SPMM_NO_EDGE"]
 variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[1:]] or [{}]
 dev = torch.device("cuda:0")
 N, E, d = 5_000_000, 100_000_000, int(os.environ.get("SWEEP_D", "128"))
@@ -28,7 +28,8 @@ for rnd in range(ROUNDS):
     for i, v in enumerate(variants):
         for k in KEYS:
             os.environ.pop(k, None)
-        os.environ.update({("LPG_SPMM_" + k if not k.startswith("LPG_") else k): val for k, val in v.items()})
+        os.environ.update({("LPG_SPMM_" + k if not k.startswith("LPG_") else k): val for k, val in v.items() if val != ""})
+        g._build_plan()                      # the plan depends on the chunk size
         for _ in range(2):
             g.spmm(x)
         torch.cuda.synchronize()

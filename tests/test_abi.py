@@ -26,7 +26,7 @@ def test_workspace_queries_and_errors():
     assert lib.lpg_abi_version() == 1
     assert lib.lpg_spmm_chunk_edges(1000) == 16 and lib.lpg_spmm_chunk_edges(100_000_000) == 512
     T = lib.lpg_spmm_chunk_edges(5_000_000)
-    assert T % 64 == 0 and lib.lpg_csr_spmm_bytes(5_000_000, 128) == 2 * (-(-5_000_000 // T)) * 128 * 4 + 256
+    assert T % 16 == 0 and lib.lpg_csr_spmm_bytes(5_000_000, 128) == 2 * (-(-5_000_000 // T)) * 128 * 4 + 256
     assert lib.lpg_csr_spmm_bytes(-1, 128) < 0
     for q in (lib.lpg_csr_plan_bytes(100, 1000), lib.lpg_graphnorm_bytes(100, 32), lib.lpg_coo_to_csr_bytes(1000, 100, 1),
               lib.lpg_get_ei2_bytes(100, 1000, 100), lib.lpg_compact_cols_bytes(1000), lib.lpg_seal_block_csr_bytes(1000)):
