@@ -211,7 +211,10 @@ int64_t lpg_seal_block_csr_bytes(int64_t total_nodes);
 int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_nodes, const int64_t* node_off,
                           const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len,
                           int64_t T, const float* emb, int64_t emb_dim, int64_t B, float* x,
-                          int64_t ldx, int32_t* err_flag, void* stream);
+                          int64_t ldx, int zero_pad, int32_t* err_flag, void* stream);
+/* zero_pad != 0: columns [T + emb_dim, ldx) of every row are written with zeros as well.  Rows padded to a
+ * 16-byte multiple are then written as whole cache lines (a row with an unwritten tail turns every store
+ * of the kernel into a read-modify-write: 2x slower), and the pad is safe to feed to a GEMM. */
 
 /* ---------------------------------------------------------------- SEAL head
  * SortPooling [SEAL/model/gnn.py:82-91]: per subgraph b, order its n_b vertices by key (= Z_4[:,0])

@@ -445,32 +445,71 @@ __global__ __launch_bounds__(kBlock) void seal_features_kernel(const int32_t* __
                                                                const int32_t* __restrict__ tag_map, int64_t tag_map_len,
                                                                int64_t T, const float* __restrict__ emb, int64_t emb_dim,
                                                                int64_t B, float* __restrict__ x, int64_t ldx,
-                                                               int32_t* err_flag) {
+                                                               int wstore, int32_t* err_flag) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int width = static_cast<int>(T + emb_dim);
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+  const int width = static_cast<int>(T + emb_dim);     // wstore >= width: columns [width, wstore) are zero-filled
+  constexpr int R = 4;                               // rows per wave in flight: the chain node id -> emb row -> store
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {   // is three dependent round trips, so rows are batched
     const int64_t base = node_off[b];
     int n = static_cast<int>(node_off[b + 1] - base);
     if (n > MAXN) n = MAXN;
-    for (int i = wave; i < n; i += kBlock / 64) {
-      int32_t tg = tags[b * MAXN + i];
-      if (tag_map) {
-        if (tg >= 0 && tg < tag_map_len) tg = tag_map[tg];
-        else { if (lane == 0) flag_error(err_flag, LPG_F_INDEX_RANGE); tg = -1; }
+    for (int i0 = wave * R; i0 < n; i0 += (kBlock / 64) * R) {
+      // every load below comes from a clamped, always-valid address and is issued before anything looks at
+      // a value (compiler barrier): written as `cond ? load : x` hipcc branches around each load and waits for
+      // it -- 12 serialized round trips per 4 rows in the first version of this loop
+      int32_t tg[R], nd[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int i = i0 + q < n ? i0 + q : n - 1;   // clamped: the duplicate is not stored
+        tg[q] = tags[b * MAXN + i];
+        nd[q] = nodes[b * MAXN + i];
       }
-      const float* erow = emb ? emb + static_cast<int64_t>(nodes[b * MAXN + i]) * emb_dim - T : nullptr;
-      float* xrow = x + (base + i) * ldx;
-      for (int c0 = 0; c0 < width; c0 += 256) {      // 4 columns in flight per lane
-        float v[4];
+      asm volatile("" ::: "memory");
+      if (tag_map && tag_map_len <= 0) {             // uniform: an empty map maps nothing
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = c0 + u * 64 + lane;
-          v[u] = (c >= T && c < width) ? erow[c] : ((tg == c) ? 1.f : 0.f);
+        for (int q = 0; q < R; ++q) tg[q] = -1;
+        if (lane == 0) flag_error(err_flag, LPG_F_INDEX_RANGE);
+      } else if (tag_map) {
+        int32_t tm[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) tm[q] = tag_map[(tg[q] >= 0 && tg[q] < tag_map_len) ? tg[q] : 0];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const bool ok = tg[q] >= 0 && tg[q] < tag_map_len;
+          if (!ok && lane == 0 && i0 + q < n) flag_error(err_flag, LPG_F_INDEX_RANGE);
+          tg[q] = ok ? tm[q] : -1;
         }
+      }
+      const float* ebase = emb_dim > 0 ? emb : x;    // emb_dim == 0: any valid address, the value is never used
+      for (int c0 = 0; c0 < wstore; c0 += 192) {     // 3 columns x R rows in flight per lane
+        float v[R][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = c0 + u * 64 + lane;
-          if (c < width) xrow[c] = v[u];
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int c = c0 + u * 64 + lane;
+            const bool is_emb = c >= T && c < width;
+            v[q][u] = ebase[is_emb ? static_cast<int64_t>(nd[q]) * emb_dim + (c - static_cast<int>(T)) : 0];
+          }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int c = c0 + u * 64 + lane;
+            const bool is_emb = c >= T && c < width;
+            v[q][u] = is_emb ? v[q][u] : ((tg[q] == c) ? 1.f : 0.f);
+          }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          if (i0 + q >= n) continue;
+          float* xrow = x + (base + i0 + q) * ldx;
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int c = c0 + u * 64 + lane;
+            if (c < wstore) xrow[c] = v[q][u];
+          }
         }
       }
     }
@@ -480,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void seal_features_kernel(const int32_t* __
 __global__ __launch_bounds__(kSealBlock) void seal_sortpool_kernel(const float* __restrict__ z, int64_t ldz,
                                                                    const float* __restrict__ key,
                                                                    const int64_t* __restrict__ node_off, int64_t B,
-                                                                   int64_t k, int64_t C, float* __restrict__ out) {
+                                                                   int64_t k, int64_t C, float* __restrict__ out, int vec) {
   __shared__ float keys[MAXN];
   __shared__ int order[MAXN];     // order[rank] = vertex
   const int t = threadIdx.x;
@@ -501,10 +540,30 @@ __global__ __launch_bounds__(kSealBlock) void seal_sortpool_kernel(const float* 
       order[rank] = t;
     }
     __syncthreads();
-    const int64_t total = k * C;
-    for (int64_t q = t; q < total; q += kSealBlock) {
-      const int64_t r = q / C, c = q - r * C;
-      out[(b * k + r) * C + c] = r < n ? z[(base + order[r]) * ldz + c] : 0.f;
+    if (vec) {                                       // C % 4 == 0, 16-byte aligned rows: whole float4 pieces
+      const int C4 = static_cast<int>(C) / 4, total = static_cast<int>(k) * C4;
+      float4* ob = reinterpret_cast<float4*>(out + b * k * C);
+      for (int q0 = t; q0 < total; q0 += 4 * kSealBlock) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u * kSealBlock, r = q / C4, c = q - r * C4;
+          const bool ok = q < total && r < n;
+          const float4 t4 = *reinterpret_cast<const float4*>(z + (base + (ok ? order[r] : 0)) * ldz + (ok ? c * 4 : 0));
+          v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u * kSealBlock;
+          if (q < total) ob[q] = v[u];
+        }
+      }
+    } else {
+      const int total = static_cast<int>(k * C), Ci = static_cast<int>(C);
+      for (int q = t; q < total; q += kSealBlock) {
+        const int r = q / Ci, c = q - r * Ci;
+        out[b * k * C + q] = r < n ? z[(base + order[r]) * ldz + c] : 0.f;
+      }
     }
   }
 }
@@ -577,16 +636,17 @@ LPG_EXPORT int lpg_seal_block_csr(const int32_t* n_nodes, const int64_t* node_of
 
 LPG_EXPORT int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_nodes, const int64_t* node_off,
                                      const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len, int64_t T,
-                                     const float* emb, int64_t emb_dim, int64_t B, float* x, int64_t ldx,
+                                     const float* emb, int64_t emb_dim, int64_t B, float* x, int64_t ldx, int zero_pad,
                                      int32_t* err_flag, void* stream) {
   LPG_REQUIRE(B >= 0 && T >= 0 && emb_dim >= 0 && ldx >= T + emb_dim, "seal_features: bad sizes");
   (void)n_nodes;
   if (B == 0 || T + emb_dim == 0) return LPG_OK;
   LPG_REQUIRE(nodes && node_off && tags && x && (emb_dim == 0 || emb), "seal_features: null pointer");
-  LPG_REQUIRE(T + emb_dim < (int64_t(1) << 30), "seal_features: row too wide");
+  LPG_REQUIRE(ldx < (int64_t(1) << 30), "seal_features: row too wide");
+  const int wstore = static_cast<int>(zero_pad ? ldx : T + emb_dim);
   const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
   hipLaunchKernelGGL(seal_features_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), nodes, node_off, tags, tag_map,
-                     tag_map_len, T, emb, emb_dim, B, x, ldx, err_flag);
+                     tag_map_len, T, emb, emb_dim, B, x, ldx, wstore, err_flag);
   return check_launch("seal_features");
 }
 
@@ -596,8 +656,11 @@ LPG_EXPORT int lpg_seal_sortpool_f32(const float* z, int64_t ldz, const float* k
   if (B == 0) return LPG_OK;
   LPG_REQUIRE(z && key && node_off && out, "seal_sortpool: null pointer");
   const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
+  LPG_REQUIRE(k * C < (int64_t(1) << 30), "seal_sortpool: k * C too large");
+  const int vec = C % 4 == 0 && ldz % 4 == 0 && reinterpret_cast<uintptr_t>(z) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(out) % 16 == 0;
   hipLaunchKernelGGL(seal_sortpool_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), z, ldz, key, node_off, B,
-                     k, C, out);
+                     k, C, out, vec);
   return check_launch("seal_sortpool");
 }
 

@@ -237,7 +237,7 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.
     width = tags_size + emb_dim
     x = torch.empty((total, -(-width // 8) * 8), dtype=torch.float32, device=dev)[:, :width]
     _lib.check(lib.lpg_seal_features_f32(P(batch.nodes), P(batch.n), P(off), P(batch.tags), P(tag_map),
-                                         tag_map.numel(), tags_size, P(emb), emb_dim, batch.B, P(x), x.stride(0),
+                                         tag_map.numel(), tags_size, P(emb), emb_dim, batch.B, P(x), x.stride(0), 1,
                                          P(_ops.err_flag(dev)), S()), "seal_features")
     _ops.maybe_check(dev, "seal feature index")
     if dtype != torch.float32:
