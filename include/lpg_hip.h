@@ -104,18 +104,23 @@ int lpg_csr_plan_build(const int64_t* rowptr, const int32_t* col, int64_t N, int
  * chunks are finished by a second kernel that adds the partials in chunk order.
  * bf16 variant: x, y are bfloat16 (uint16 bit patterns), accumulation in fp32.
  * n_empty_hint: number of rows without edges if the caller knows it (0 skips the empty-row
- * launch), -1 = unknown (read from the plan on the device). */
+ * launch), -1 = unknown (read from the plan on the device).
+ * max_row_hint: length of the longest row if the caller knows it (the plan stores it: int32 word 1
+ * of the plan buffer, next to the empty-row count in word 0), -1 = unknown.  Short rows (<= 32) on
+ * graphs up to 2 M edges run as ONE launch with a lane group per row, added left to right (no chunk
+ * cuts, no fix-up, empty rows included); otherwise the chunked kernels.  d in {1,2,4,8,16} uses an
+ * edge-parallel kernel whose in-row additions form a fixed tree (reproducible, not left-to-right). */
 int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d);
 int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col,
                      const float* val, const float* x, int64_t ldx, float* y, int64_t ldy,
                      int64_t N, int64_t n_cols, int64_t e_cap, int64_t d, const float* row_scale,
-                     const float* bias, int act, int64_t n_empty_hint, void* workspace,
-                     int64_t workspace_bytes, void* stream);
+                     const float* bias, int act, int64_t n_empty_hint, int64_t max_row_hint,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* col,
                       const float* val, const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy,
                       int64_t N, int64_t n_cols, int64_t e_cap, int64_t d, const float* row_scale,
-                      const float* bias, int act, int64_t n_empty_hint, void* workspace,
-                      int64_t workspace_bytes, void* stream);
+                      const float* bias, int act, int64_t n_empty_hint, int64_t max_row_hint,
+                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- dense feature linear (K5)
  * Y[n,m] = X[n,k] @ W^T (+ bias), W is [m,k] (nn.Linear / GCNConv.lin layout) or, with

@@ -191,6 +191,11 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t* __restrict_
       if (lane == 0) empty_rows[atomicAdd(n_empty, 1)] = static_cast<int32_t>(r);
       continue;
     }
+    // header word 1: the longest row.  The plain read first: the maximum only grows, so a stale value can
+    // only cause a redundant atomic, and all but a few dozen rows skip it (an unconditional atomicMax on one
+    // address serialised 1.5 M rows: 16 ms)
+    if (lane == 0 && e - b > static_cast<int64_t>(__builtin_nontemporal_load(n_empty + 1)))
+      atomicMax(n_empty + 1, static_cast<int32_t>(e - b));
     for (int64_t k = b + lane; k < e; k += 64) {
       rowid[k] = static_cast<int32_t>(r);
       const int32_t c = col[k];

@@ -7,6 +7,8 @@
 // (2) one block folds the partials in block order and emits per-column shift/scale/bias,
 // (3) elementwise apply with optional fused ReLU and residual add (the conv2s + conv2s_r sum,
 // model.py:77).  fp64 sums make the one-pass variance safe: var = E[x^2] - mean^2*ms*(2-ms).
+#include <stdlib.h>
+
 #include "lpg_common.hpp"
 
 namespace {
@@ -157,6 +159,89 @@ __global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restric
   }
 }
 
+// ---- small n (<= 8192 rows): the whole op in ONE launch ------------------------------------------------
+// GraphNorm statistics are per column, so column blocks are independent: a 1024-thread workgroup owns four
+// columns (one float4 per row) of ALL rows, keeps its rows in registers (thread t: rows t, t+1024, ...), sums
+// them in fp64 (per thread in row order, then a fixed shuffle / LDS tree), derives shift / scale / bias, and
+// applies them to the registers.  The fb-pages-food forward calls GraphNorm four times on [620..6576, 32..256]
+// tensors and is launch-bound: one launch instead of three saves ~9 us per call.
+constexpr int kSmallRows = 8;        // rows per thread
+constexpr int kSmallBlock = 1024;
+__global__ __launch_bounds__(kSmallBlock) void gn_small_kernel(const float* __restrict__ x, int n, int d,
+                                                              const float* __restrict__ weight,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ mean_scale, float eps, int relu,
+                                                              const float* __restrict__ add_to, float* __restrict__ y) {
+  __shared__ double red[2][kSmallBlock / 64][4];
+  __shared__ float st[3][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int c = blockIdx.x * 4;
+  float4 v[kSmallRows], a[kSmallRows];
+#pragma unroll
+  for (int k = 0; k < kSmallRows; ++k) {             // every load first (clamped rows), then the arithmetic
+    const int r = t + k * kSmallBlock;
+    const int64_t off = static_cast<int64_t>(r < n ? r : n - 1) * d + c;
+    v[k] = *reinterpret_cast<const float4*>(x + off);
+  }
+  asm volatile("" ::: "memory");
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < kSmallRows; ++k) {
+    if (t + k * kSmallBlock < n) {
+      const double q[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[i] += q[i]; s2[i] += q[i] * q[i]; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s[i] += __shfl_xor(s[i], o);
+      s2[i] += __shfl_xor(s2[i], o);
+    }
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[0][wave][i] = s[i]; red[1][wave][i] = s2[i]; }
+#pragma unroll
+  for (int k = 0; k < kSmallRows; ++k) {             // the residual rows fly during the barrier and the finalize
+    const int r = t + k * kSmallBlock;
+    const int64_t off = static_cast<int64_t>(r < n ? r : n - 1) * d + c;
+    a[k] = add_to ? *reinterpret_cast<const float4*>(add_to + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  if (t < 4) {
+    double ts = 0.0, ts2 = 0.0;
+    for (int w = 0; w < kSmallBlock / 64; ++w) { ts += red[0][w][t]; ts2 += red[1][w][t]; }   // fixed order
+    const double mean = ts / static_cast<double>(n), ex2 = ts2 / static_cast<double>(n);
+    const double ms = mean_scale ? static_cast<double>(mean_scale[c + t]) : 1.0;
+    double var = ex2 - mean * mean * ms * (2.0 - ms);
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + static_cast<double>(eps));
+    st[0][t] = static_cast<float>(mean * ms);
+    st[1][t] = static_cast<float>((weight ? static_cast<double>(weight[c + t]) : 1.0) * inv);
+    st[2][t] = bias ? bias[c + t] : 0.f;
+  }
+  __syncthreads();
+  const float sh[4] = {st[0][0], st[0][1], st[0][2], st[0][3]}, sc[4] = {st[1][0], st[1][1], st[1][2], st[1][3]},
+              bi[4] = {st[2][0], st[2][1], st[2][2], st[2][3]};
+#pragma unroll
+  for (int k = 0; k < kSmallRows; ++k) {
+    const int r = t + k * kSmallBlock;
+    if (r < n) {
+      const float q[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, ad[4] = {a[k].x, a[k].y, a[k].z, a[k].w};
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float w = (q[i] - sh[i]) * sc[i] + bi[i];
+        if (relu) w = w > 0.f ? w : 0.f;
+        o[i] = w + ad[i];
+      }
+      *reinterpret_cast<float4*>(y + static_cast<int64_t>(r) * d + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 inline int part_blocks(int64_t n, int64_t* rows_per_block) {
   int64_t rpb = ceil_div(n, kMaxPartBlocks);
   if (rpb < 8) rpb = 8;           // small n: many short blocks (each thread's row loop is a latency chain)
@@ -181,6 +266,16 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
     return LPG_E_WORKSPACE;
   }
   hipStream_t st = as_stream(stream);
+  {
+    auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    const char* env = getenv("LPG_GN_SMALL");          // A/B hook: 0 keeps the three-launch path
+    if (n <= kSmallRows * kSmallBlock && d % 4 == 0 && d / 4 < 65536 && al16(x) && al16(y) && (!add_to || al16(add_to)) &&
+        !(env && atoi(env) == 0)) {
+      hipLaunchKernelGGL(gn_small_kernel, dim3(static_cast<unsigned>(d / 4)), dim3(kSmallBlock), 0, st, x,
+                         static_cast<int>(n), static_cast<int>(d), weight, bias, mean_scale, eps, relu, add_to, y);
+      return check_launch("graphnorm (one launch)");
+    }
+  }
   double* part = static_cast<double*>(workspace);
   float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + static_cast<int64_t>(kMaxPartBlocks) * 2 * d * 8);
   int64_t rpb;

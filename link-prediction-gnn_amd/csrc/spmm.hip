@@ -356,6 +356,88 @@ __global__ __launch_bounds__(kBlock) void spmm_main_kernel(const SpmmArgs a) {
   if (open_right && lane_on) carry_store<VEC>(carry0 + ((first_seg && open_left) ? 0 : a.dpad), acc);
 }
 
+// ---- short rows, known on the host: one group of G lanes per ROW ---------------------------------------
+// When the plan's longest row is short (max_row_hint <= 32) a row never needs to be cut: a group walks its row left to right, U gathers
+// in flight, stores once with the epilogue -- no carry slots, no fix-up launch, and empty rows get act(bias)
+// from the same kernel.  One launch instead of two or three: the fb-pages-food forward is launch-bound.
+// Sum order: CSR order inside the row == oracle/spmm_ref.c with a chunk at least as long as the row.
+template <typename T, int VEC, int G, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
+  constexpr int GPW = kWave / G;
+  constexpr int U = G < 8 ? G : 8;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t row = wave * GPW + lane / G;
+  const bool row_on = row < a.N;
+  int64_t c0 = static_cast<int64_t>(blockIdx.y) * (G * VEC) + gl * VEC;
+  const bool lane_on = row_on && c0 < a.d;
+  if (c0 >= a.d) c0 = 0;
+  const T* xb = static_cast<const T*>(a.x) + c0;
+  const int64_t beg = row_on ? a.rowptr[row] : 0;
+  const int64_t end = row_on ? a.rowptr[row + 1] : 0;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  for (int64_t e0 = beg; __any(e0 < end); e0 += G) {
+    const int64_t e = e0 + gl;
+    const bool in = e < end;
+    const int c = in ? a.col[e] : 0;
+    float w = 0.f;
+    if constexpr (WEIGHTED) w = in ? a.val[e] : 0.f;
+#pragma unroll 1
+    for (int j0 = 0; j0 < G; j0 += U) {
+      if (!__any(e0 + j0 < end)) break;
+      typename Piece<T, VEC>::Raw raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cj = __shfl(c, j0 + u, G);
+        raw[u] = Piece<T, VEC>::load(xb + static_cast<int64_t>(cj) * a.ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = e0 + j0 + u < end;
+        float v[VEC];
+        Piece<T, VEC>::widen(raw[u], v);
+        if constexpr (WEIGHTED) {
+          const float wj = __shfl(w, j0 + u, G);       // 0 past the row's end
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wj, ok ? v[i] : 0.f, acc[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += ok ? v[i] : 0.f;
+        }
+      }
+    }
+  }
+  if (lane_on) {
+    if (a.row_scale || a.bias || a.act != LPG_ACT_NONE) store_out<T, VEC, true>(a, row, c0, acc);
+    else store_out<T, VEC, false>(a, row, c0, acc);
+  }
+}
+
+template <typename T, int VEC, int G>
+int launch_rows_g(const SpmmArgs& a, hipStream_t st) {
+  constexpr int GPW = kWave / G;
+  const int64_t n_blocks = ceil_div(ceil_div(a.N, GPW), kBlock / kWave);
+  const int64_t tiles = ceil_div(a.d, G * VEC);
+  LPG_REQUIRE(n_blocks < (int64_t(1) << 31) && tiles < 65536, "csr_spmm: grid too large");
+  const dim3 grid(static_cast<unsigned>(n_blocks), static_cast<unsigned>(tiles));
+  if (a.val) hipLaunchKernelGGL((spmm_rows_kernel<T, VEC, G, true>), grid, dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((spmm_rows_kernel<T, VEC, G, false>), grid, dim3(kBlock), 0, st, a);
+  return LPG_OK;
+}
+template <typename T, int VEC>
+int launch_rows(const SpmmArgs& a, hipStream_t st) {
+  const int64_t lanes = ceil_div(a.d, VEC);
+  if (lanes <= 2) return launch_rows_g<T, VEC, 2>(a, st);
+  if (lanes <= 4) return launch_rows_g<T, VEC, 4>(a, st);
+  if (lanes <= 8) return launch_rows_g<T, VEC, 8>(a, st);
+  if (lanes <= 16) return launch_rows_g<T, VEC, 16>(a, st);
+  if (lanes <= 32) return launch_rows_g<T, VEC, 32>(a, st);
+  return launch_rows_g<T, VEC, 64>(a, st);
+}
+
 // ---- narrow features (d = 1, 2, 4, 8, 16): lanes are EDGES, not feature columns ---------------------------
 // With d <= 4 the main kernel's "G lanes per chunk" degenerates to one lane walking a chunk alone (64 chunks
 // per wave, every index load 64 cache lines wide, a row flush on almost every step): 0.5 ms for the 8.5 M-edge
@@ -614,8 +696,8 @@ int launch_vec(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
 template <typename T, int WIDE>
 int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val, const T* x,
                int64_t ldx, T* y, int64_t ldy, int64_t N, int64_t n_cols, int64_t e_cap, int64_t d, const float* row_scale,
-               const float* bias, int act, int64_t n_empty_hint, void* workspace, int64_t workspace_bytes,
-               void* stream) {
+               const float* bias, int act, int64_t n_empty_hint, int64_t max_row_hint, void* workspace,
+               int64_t workspace_bytes, void* stream) {
   LPG_REQUIRE(N >= 0 && e_cap >= 0 && d >= 1, "csr_spmm: bad sizes N=%lld e_cap=%lld d=%lld", (long long)N,
               (long long)e_cap, (long long)d);
   if (N == 0) return LPG_OK;
@@ -641,6 +723,19 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
   a.chunk = chunk_for(e_cap);
   a.off32 = (n_cols > 0 && static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * sizeof(T) <= (uint64_t(1) << 32)) ? 1 : 0;
   if (!tune().off32) a.off32 = 0;
+  // short rows (host knows the longest), 16-byte rows, not a huge graph: one launch, a group per row
+  const bool wide_all = d % WIDE == 0 && ldx % WIDE == 0 && ldy % WIDE == 0 &&
+                        reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+  // a group walks its row alone, so the kernel takes as long as the LONGEST row: worth it only for really short
+  // rows (fb-pages-food's graphs have rows of ~110 edges and are faster on the chunked kernels, 110 vs 116 us / forward)
+  const int rows_max = getenv("LPG_SPMM_ROWS_MAX") ? atoi(getenv("LPG_SPMM_ROWS_MAX")) : 32;    // 0 disables (A/B)
+  const int64_t rows_ecap = getenv("LPG_SPMM_ROWS_ECAP") ? atoll(getenv("LPG_SPMM_ROWS_ECAP")) : (int64_t(1) << 21);
+  if (max_row_hint >= 0 && max_row_hint <= rows_max && wide_all && d / WIDE >= 2 && e_cap <= rows_ecap &&
+      tune().mode == 0) {
+    const int rc = launch_rows<T, WIDE>(a, st);
+    if (rc != LPG_OK) return rc;
+    return check_launch("csr_spmm (rows)");
+  }
   // d <= 16 in a power of two: the edge-parallel kernel (lanes = edges); wider rows: lanes = feature columns
   const bool narrow = (d == 1 || d == 2 || d == 4 || d == 8 || d == 16) && tune().mode == 0 && !getenv("LPG_SPMM_NO_EDGE");
   if (e_cap > 0 && narrow) {
@@ -694,15 +789,17 @@ LPG_EXPORT int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d) {
 LPG_EXPORT int lpg_csr_spmm_f32(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,
                                 const float* x, int64_t ldx, float* y, int64_t ldy, int64_t N, int64_t n_cols,
                                 int64_t e_cap, int64_t d, const float* row_scale, const float* bias, int act,
-                                int64_t n_empty_hint, void* workspace, int64_t workspace_bytes, void* stream) {
+                                int64_t n_empty_hint, int64_t max_row_hint, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
   return spmm_entry<float, 4>(plan, rowptr, col, val, x, ldx, y, ldy, N, n_cols, e_cap, d, row_scale, bias, act, n_empty_hint,
-                              workspace, workspace_bytes, stream);
+                              max_row_hint, workspace, workspace_bytes, stream);
 }
 
 LPG_EXPORT int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* col, const float* val,
                                  const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t N, int64_t n_cols,
                                  int64_t e_cap, int64_t d, const float* row_scale, const float* bias, int act,
-                                 int64_t n_empty_hint, void* workspace, int64_t workspace_bytes, void* stream) {
+                                 int64_t n_empty_hint, int64_t max_row_hint, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
   return spmm_entry<uint16_t, 8>(plan, rowptr, col, val, x, ldx, y, ldy, N, n_cols, e_cap, d, row_scale, bias, act,
-                                 n_empty_hint, workspace, workspace_bytes, stream);
+                                 n_empty_hint, max_row_hint, workspace, workspace_bytes, stream);
 }

@@ -103,6 +103,7 @@ class CSRGraph:
         self._plan = None
         self._ws = {}
         self.n_empty = -1          # rows without edges, once known on the host (0 skips a launch)
+        self.max_row = -1          # longest row, once known on the host (short rows: one-launch row-parallel SpMM)
 
     # -- construction ----------------------------------------------------------------------
     @staticmethod
@@ -157,7 +158,8 @@ class CSRGraph:
     def _finish_build(self, what):
         """the single host sync of a graph build: error flag + number of empty rows."""
         raise_if_flagged(self.device, what)
-        self.n_empty = int(self._plan[:4].view(torch.int32).item())
+        head = self._plan[:8].view(torch.int32).tolist()
+        self.n_empty, self.max_row = int(head[0]), int(head[1])
 
     def gcn_normalize_(self):
         """val <- D^-1/2 val D^-1/2 with D = destination weight sums (PyG gcn_norm)."""
@@ -202,7 +204,7 @@ class CSRGraph:
         ws, nbytes = self._workspace(d)
         args = (_ptr(self._plan), _ptr(self.rowptr), _ptr(self.col), _ptr(val), _ptr(x), x.stride(0), _ptr(out),
                 out.stride(0), self.n_rows, self.n_cols, self.e_cap, d, _ptr(row_scale), _ptr(bias), ACT[act], self.n_empty,
-                _ptr(ws), nbytes, _stream())
+                self.max_row, _ptr(ws), nbytes, _stream())
         if x.dtype == torch.float32:
             _lib.check(lib.lpg_csr_spmm_f32(*args), "csr_spmm_f32")
         elif x.dtype == torch.bfloat16:

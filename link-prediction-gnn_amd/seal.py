@@ -231,6 +231,7 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.
     g = _ops.CSRGraph(rowptr, col[:nnz] if nnz else col, val[:nnz] if nnz else val, total, total, nnz)
     g._build_plan()
     g.n_empty = 0                       # A~ = A + I: every row holds its diagonal
+    g.max_row = 129                     # <= LPG_SEAL_MAXN neighbours + the diagonal (known without a sync)
     g.rows_prescaled = bool(fold_dinv)
     emb_dim = 0 if emb is None else emb.shape[1]
     emb = None if emb is None else _ops._c(emb, torch.float32)

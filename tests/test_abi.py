@@ -31,7 +31,7 @@ def test_workspace_queries_and_errors():
     for q in (lib.lpg_csr_plan_bytes(100, 1000), lib.lpg_graphnorm_bytes(100, 32), lib.lpg_coo_to_csr_bytes(1000, 100, 1),
               lib.lpg_get_ei2_bytes(100, 1000, 100), lib.lpg_compact_cols_bytes(1000), lib.lpg_seal_block_csr_bytes(1000)):
         assert q > 0
-    rc = lib.lpg_csr_spmm_f32(0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 10, 0, 0, 0, 0, -1, 0, 0, 0)
+    rc = lib.lpg_csr_spmm_f32(0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 10, 0, 0, 0, 0, -1, -1, 0, 0, 0)
     assert rc == -1 and b"bad sizes" in lib.lpg_last_error()
     rc = lib.lpg_seal_subgraphs(0, 0, 10, 0, 4, 2, 100, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     assert rc == -1 and b"hop" in lib.lpg_last_error()

@@ -853,6 +853,34 @@ def test_spmm_bit_exact_vs_same_order_c_loop(dev, d, weighted):
     assert np.array_equal(y, want), float(np.abs(y - want).max())
 
 
+@pytest.mark.parametrize("d,weighted", [(32, True), (128, False), (8, True), (256, True)])
+def test_spmm_short_rows_single_launch_bit_exact(dev, monkeypatch, d, weighted):
+    """short rows known on the host => the one-launch row-parallel kernel: CSR order inside every row, i.e. the
+    same-order C loop with a chunk longer than any row, bit for bit; empty rows carry act(bias)."""
+    import lpgnn_amd
+    from oracle import aggregation as agg, spmm_c
+    monkeypatch.setenv("LPG_SPMM_ROWS_MAX", "512")          # default 32: this graph's longest row is ~30-40
+    rng = np.random.default_rng(70 + d)
+    n_rows, n_cols, E = 3000, 2500, 40000
+    ei = rand_graph(rng, n_rows, n_cols, E, hub=0.0, empty_frac=0.1)
+    w = rng.standard_normal(ei.shape[1]).astype(np.float32) if weighted else None
+    x = rng.standard_normal((n_cols, d)).astype(np.float32)
+    g = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n_rows, n_cols,
+                                           None if w is None else torch.from_numpy(w).to(dev))
+    rowptr, col, val, _ = agg.coo_to_csr(ei[1], ei[0], n_rows, w)
+    assert g.max_row == int(np.diff(rowptr).max()) and 0 < g.max_row <= 512 and g.n_empty == int((np.diff(rowptr) == 0).sum())
+    y = _np(g.spmm(torch.from_numpy(x).to(dev)))
+    want = spmm_c.spmm_f32_chunked(rowptr, col, val, x, 1 << 30)
+    assert np.array_equal(y, want), float(np.abs(y - want).max())
+    b = rng.standard_normal(d).astype(np.float32)
+    yb = _np(g.spmm(torch.from_numpy(x).to(dev), bias=torch.from_numpy(b).to(dev), act="relu"))
+    assert np.array_equal(yb, np.maximum(want + b, 0).astype(np.float32))
+    g.max_row = -1                                         # unknown => the chunked kernels: same values up to rounding order
+    y2 = _np(g.spmm(torch.from_numpy(x).to(dev)))
+    mag = agg.spmm_abs_rowsum(rowptr, col, val, x)
+    assert np.all(np.abs(y2 - want) <= TOL * mag + 1e-30)
+
+
 def test_zero_size_inputs_everywhere(dev):
     """empty inputs through every public op: no launch, no fault, well-formed empty/zero outputs."""
     import lpgnn_amd
