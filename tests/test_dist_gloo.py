@@ -121,6 +121,43 @@ def test_scored_edge_sharding_world2():
         assert res[0][B][2] == want[a0:b0] and res[1][B][2] == want[a1:b1]
 
 
+def _combine_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    mine = {"scored_edges": 200, "ms_per_forward": 2.0 + rank, "scored_edges_per_s": 0.0}
+    ok = bench.combine_over_ranks(mine, world, rank, timeout_s=30)
+    mine2 = {"error": "boom"} if rank == 1 else {"scored_edges": 200, "ms_per_forward": 1.0, "scored_edges_per_s": 0.0}
+    dist.barrier()
+    from torch.distributed import distributed_c10d as c10d
+    store = c10d._get_default_store()
+    store.set(f"lpg_seal_sharded_{rank}", __import__("json").dumps(mine2))       # second round: rank 1 reports a failure
+    dist.barrier()
+    bad = bench.combine_over_ranks(mine2, world, rank, timeout_s=30)
+    q.put((rank, ok, bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_combines_secondary_figure_through_the_store_world2():
+    """bench.py's sharded-SEAL figure is combined without NCCL collectives: slowest rank wins, a failed rank
+    turns into an error field instead of a hang."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_combine_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (ok, bad) for r, ok, bad in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ok0, bad0 = res[0]
+    assert ok0["ms_per_forward"] == 3.0 and abs(ok0["scored_edges_per_s"] - 200 / 3e-3) < 1e-6
+    assert "error" in bad0 and bad0["ranks_failed"] == 1
+
+
 def test_ranges_cover_and_balance():
     from lpgnn_amd import dist as ldist
     for n, w in [(10, 3), (5_000_000, 8), (7, 8), (1, 1)]:
