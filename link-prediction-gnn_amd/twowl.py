@@ -18,8 +18,10 @@ from .torch_scatter import scatter_add
 
 
 def degree(ei, num_node: int):
-    """TwoWL/utils.py:8-10 -- in-degree histogram over ei[1]; int64, bit-exact."""
-    return scatter_add(torch.ones_like(ei[1]), ei[1], dim_size=num_node)
+    """TwoWL/utils.py:8-10 -- in-degree histogram over ei[1]; int64, bit-exact.  Same result as the
+    reference's scatter_add(ones_like(ei[1]), ei[1], dim_size=N) (which torch_scatter.scatter_add still offers,
+    TorchScript-callable), without materialising the ones; big edge lists are counted by sorting."""
+    return _ops.degree(ei[1], num_node)
 
 
 def reverse(edge_index):

@@ -48,6 +48,32 @@ def test_degree_bit_exact(dev):
         assert got.dtype == torch.int64 and np.array_equal(_np(got), twowl_int.degree(ei, n))
 
 
+def test_degree_sorted_path_bit_exact(dev):
+    """E >= 4 M takes the sort-and-count path (csrc/degree.hip): equal to numpy's bincount and to the atomic
+    kernels, including odd lengths, a hub destination, empty nodes and out-of-range indices (skipped + flagged)."""
+    import lpgnn_amd
+    from lpgnn_amd import ops
+    from lpgnn_amd.torch_scatter import scatter_add
+    rng = np.random.default_rng(5)
+    n, E = 300_001, (1 << 22) + 12345
+    idx = rng.integers(0, n, size=E).astype(np.int64)
+    idx[: E // 10] = 777                                   # a hub
+    idx[idx % 5 == 3] = 4                                  # many empty nodes
+    t = torch.from_numpy(idx).to(dev)
+    got = ops.degree(t, n)
+    want = np.bincount(idx, minlength=n)
+    assert got.dtype == torch.int64 and np.array_equal(_np(got), want)
+    assert torch.equal(scatter_add(torch.ones_like(t), t, dim_size=n), got)        # the atomic kernels agree
+    assert torch.equal(ops.degree(t[1:], n), torch.from_numpy(np.bincount(idx[1:], minlength=n)).to(dev))   # 8-byte aligned view
+    bad = t.clone()
+    bad[123] = n + 5
+    bad[456] = -1
+    with pytest.raises(IndexError):
+        ops.degree(bad, n)
+    lib = lpgnn_amd.load_library()
+    assert lib.lpg_degree_i64_bytes(E, n) > 8 * E and lib.lpg_degree_i64_bytes(-1, 5) < 0
+
+
 def test_scatter_add_variants(dev):
     from lpgnn_amd.torch_scatter import scatter_add
     from oracle import aggregation as agg
