@@ -172,35 +172,101 @@ __global__ __launch_bounds__(kBlock) void gcn_scale_kernel(const int64_t* __rest
   }
 }
 
-// ---- plan: per-edge row ids + list of empty rows (+ column range check)
-__global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t* __restrict__ rowptr,
-                                                      const int32_t* __restrict__ col, int64_t N, int64_t n_cols,
-                                                      int64_t e_cap, int32_t* __restrict__ n_empty,
-                                                      int32_t* __restrict__ rowid, int32_t* __restrict__ empty_rows,
-                                                      int32_t* err_flag) {
+// ---- plan: per-edge row ids + list of empty rows + longest row (+ column range check)
+// Two kernels.  plan_rows_kernel is row-parallel (a lane per row): validates rowptr, lists the empty rows (one
+// atomic per wave reserves the slots) and records the longest row.  plan_edges_kernel is EDGE-balanced: a wave
+// owns 1024 consecutive edges, finds the row of its first edge by one binary search in rowptr and then slides
+// a window of 64 row starts over the rows its edges cover; the row of an edge is a 6-step search over the
+// window (ds_bpermute), col reads and row-id writes are coalesced.  Balancing by rows does not work on RMAT:
+// the 64 lowest ids hold ~3 % of all edges (26.8 ms for |E| = 100 M with a wave per row or per 64 rows).
+__global__ __launch_bounds__(kBlock) void plan_rows_kernel(const int64_t* __restrict__ rowptr, int64_t N, int64_t e_cap,
+                                                           int32_t* __restrict__ n_empty,
+                                                           int32_t* __restrict__ empty_rows, int32_t* err_flag) {
+  __shared__ int cnt[kBlock / 64];
+  __shared__ int blk_base;
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  int wave_max = 0;
+  // (the loop bound is block-uniform: every thread of a workgroup reaches the barriers the same number of times)
+  for (int64_t rb = static_cast<int64_t>(blockIdx.x) * kBlock; rb < N; rb += stride) {
+    const int64_t r0 = rb + (threadIdx.x & ~63);
+    const int64_t r = r0 + lane;
+    const bool on = r < N;
+    int64_t b = on ? rowptr[r] : 0, e = on ? rowptr[r + 1] : 0;
+    if (on && (b < 0 || e < b || e > e_cap)) { flag_error(err_flag, LPG_F_INDEX_RANGE); b = e = 0; }
+    const bool empty = on && e == b;
+    const unsigned long long em = __ballot(empty);
+    // slots for the empty rows: ONE atomic per workgroup (RMAT leaves 42 % of the rows empty, so every wave has
+    // some; a returning atomic per wave on one address serialised 78 K waves: 4 of the 6 ms of this kernel)
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) cnt[wv] = __popcll(em);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+#pragma unroll
+      for (int i = 0; i < kBlock / 64; ++i) { const int c = cnt[i]; cnt[i] = tot; tot += c; }
+      blk_base = tot ? atomicAdd(n_empty, tot) : 0;
+    }
+    __syncthreads();
+    if (empty) empty_rows[blk_base + cnt[wv] + __popcll(em & ((1ull << lane) - 1ull))] = static_cast<int32_t>(r);
+    int len = on ? static_cast<int>(e - b) : 0;       // the longest row: running maximum per wave ...
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
+    wave_max = max(wave_max, len);
+    __syncthreads();                                  // cnt / blk_base are reused by the next sweep
+  }
+  // ... folded into one of 32 header slots at the end (words 2..33; plan_edges_kernel reduces them into word 1).
+  // One slot hammered by every wave at kernel start cost 0.1 ms of serialised atomics on a 1.5 M-row graph.
+  if (lane == 0 && wave_max > 0) atomicMax(n_empty + 2 + (blockIdx.x & 31), wave_max);
+}
+
+constexpr int kPlanChunk = 1024;
+__global__ __launch_bounds__(kBlock) void plan_edges_kernel(const int64_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col, int64_t N, int64_t n_cols,
+                                                            int64_t e_cap, int32_t* __restrict__ rowid,
+                                                            int32_t* __restrict__ hdr, int32_t* err_flag) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
-  for (int64_t r = wave; r < N; r += nwaves) {
-    int64_t b = rowptr[r], e = rowptr[r + 1];
-    if (b < 0 || e < b || e > e_cap) {  // malformed rowptr: never index with it
-      if (lane == 0) flag_error(err_flag, LPG_F_INDEX_RANGE);
-      continue;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {         // header word 1 = the longest row (32 slots of plan_rows_kernel)
+    int m = 0;
+    for (int i = 0; i < 32; ++i) m = max(m, hdr[2 + i]);
+    hdr[1] = m;
+  }
+  int64_t E = rowptr[N];
+  E = E < 0 ? 0 : (E > e_cap ? e_cap : E);
+  int64_t k = wave * kPlanChunk;
+  if (k >= E) return;
+  const int64_t k_end = k + kPlanChunk < E ? k + kPlanChunk : E;
+  int64_t lo = 0, hi = N;                            // last row whose start is <= k (wave-uniform search)
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= k) lo = mid; else hi = mid;
+  }
+  int64_t r0 = lo;
+  while (k < k_end && r0 < N) {
+    const int64_t ri = r0 + lane;
+    int64_t start = rowptr[ri < N ? ri : N];
+    start = start < 0 ? 0 : (start > E ? E : start);            // a malformed rowptr was flagged by plan_rows_kernel
+    const int64_t w_last = __shfl(start, 63, 64);
+    if (w_last <= k) { r0 += 63; continue; }         // 63 rows without an edge at or after k (empty rows)
+    const int64_t w_end = w_last < k_end ? w_last : k_end;
+    for (int64_t kk = k; kk < w_end; kk += 64) {
+      const int64_t ed = kk + lane;
+      int i = 0;                                     // last i in [0, 62] with start[i] <= ed
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) {
+        const int j = i + step < 63 ? i + step : 62;
+        const int64_t sv = __shfl(start, j, 64);
+        if (i + step < 63 && sv <= ed) i += step;
+      }
+      if (ed < w_end) {
+        rowid[ed] = static_cast<int32_t>(r0 + i);
+        const int32_t c = col[ed];
+        if (c < 0 || c >= n_cols) flag_error(err_flag, LPG_F_INDEX_RANGE);
+      }
     }
-    if (e == b) {
-      if (lane == 0) empty_rows[atomicAdd(n_empty, 1)] = static_cast<int32_t>(r);
-      continue;
-    }
-    // header word 1: the longest row.  The plain read first: the maximum only grows, so a stale value can
-    // only cause a redundant atomic, and all but a few dozen rows skip it (an unconditional atomicMax on one
-    // address serialised 1.5 M rows: 16 ms)
-    if (lane == 0 && e - b > static_cast<int64_t>(__builtin_nontemporal_load(n_empty + 1)))
-      atomicMax(n_empty + 1, static_cast<int32_t>(e - b));
-    for (int64_t k = b + lane; k < e; k += 64) {
-      rowid[k] = static_cast<int32_t>(r);
-      const int32_t c = col[k];
-      if (c < 0 || c >= n_cols) flag_error(err_flag, LPG_F_INDEX_RANGE);
-    }
+    k = w_end;
+    r0 += 63;
   }
 }
 }  // namespace
@@ -277,8 +343,14 @@ LPG_EXPORT int lpg_csr_plan_build(const int64_t* rowptr, const int32_t* col, int
   int32_t* rowid = reinterpret_cast<int32_t*>(p + 256);
   int32_t* empty_rows = reinterpret_cast<int32_t*>(p + 256 + align_up((e_cap + 1) * 4, 256));
   LPG_HIP(hipMemsetAsync(p, 0, 256, st));
-  if (N > 0)
-    hipLaunchKernelGGL(plan_kernel, dim3(grid_for(N * 64)), dim3(kBlock), 0, st, rowptr, col, N, n_cols, e_cap,
-                       n_empty, rowid, empty_rows, err_flag);
+  if (N > 0) {
+    hipLaunchKernelGGL(plan_rows_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st, rowptr, N, e_cap, n_empty, empty_rows,
+                       err_flag);
+    if (e_cap > 0) {
+      const int64_t waves = ceil_div(e_cap, kPlanChunk);
+      hipLaunchKernelGGL(plan_edges_kernel, dim3(static_cast<unsigned>(ceil_div(waves, kBlock / kWave))), dim3(kBlock), 0,
+                         st, rowptr, col, N, n_cols, e_cap, rowid, n_empty, err_flag);
+    }
+  }
   return check_launch("csr_plan_build");
 }
