@@ -219,6 +219,20 @@ def test_spmm_bf16(dev, d):
     _check_spmm(dev, np.random.default_rng(30 + d), 2000, 2000, 50000, d, d % 16 == 0, hub=0.2, dtype=torch.bfloat16)
 
 
+@pytest.mark.parametrize("chunk", ["16", "128", "512"])
+@pytest.mark.parametrize("d,dtype", [(1, torch.float32), (2, torch.float32), (4, torch.float32), (16, torch.float32),
+                                     (1, torch.bfloat16), (4, torch.bfloat16), (16, torch.bfloat16)])
+def test_spmm_edge_parallel_kernel_long_chunks(dev, monkeypatch, chunk, d, dtype):
+    """d in {1,2,4,8,16} runs the edge-parallel kernel (lanes = edges, segmented scan).  Chunks longer than one
+    64-edge step (the big-graph setting, forced here) exercise the running sum across steps, rows that span
+    steps and chunks (a hub with a quarter of the edges), empty rows, and the epilogue (scale, bias, tanh)."""
+    monkeypatch.setenv("LPG_SPMM_CHUNK", chunk)
+    rng = np.random.default_rng(int(chunk) + d)
+    for kw in ({}, {"scale": True, "bias": True, "act": "tanh"}):
+        _check_spmm(dev, rng, 1500, 1300, 60000, d, True, hub=0.25, empty_frac=0.15, dtype=dtype, **kw)
+    _check_spmm(dev, rng, 900, 700, 20000, d, False, hub=None, empty_frac=0.0, dtype=dtype, bias=True, act="relu")
+
+
 def test_spmm_chunk_border_exhaustive(dev):
     """rows whose edge runs start / end exactly on, one before and one after chunk borders."""
     import lpgnn_amd
@@ -859,12 +873,15 @@ def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
     assert float((z16.float() - z32).abs().max()) < 0.03 and float((k16.float() - k32).abs().max()) < 0.03
 
 
+@pytest.mark.parametrize("chunk", [None, "512"])
 @pytest.mark.parametrize("d,weighted", [(128, False), (128, True), (32, True), (64, False), (3, True), (256, False)])
-def test_spmm_bit_exact_vs_same_order_c_loop(dev, d, weighted):
+def test_spmm_bit_exact_vs_same_order_c_loop(dev, monkeypatch, d, weighted, chunk):
     """the atomic-free SpMM equals a plain fp32 CPU loop that adds in the same
     order (oracle/spmm_ref.c: CSR order inside a chunk, chunk pieces left to right) BIT FOR BIT."""
     import lpgnn_amd
     from oracle import aggregation as agg, spmm_c
+    if chunk is not None:                                   # the big-graph chunk length on a small graph
+        monkeypatch.setenv("LPG_SPMM_CHUNK", chunk)
     rng = np.random.default_rng(40 + d)
     n_rows, n_cols, E = 3000, 2500, 90000
     ei = rand_graph(rng, n_rows, n_cols, E, hub=0.25, empty_frac=0.1)
