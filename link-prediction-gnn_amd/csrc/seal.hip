@@ -98,7 +98,8 @@ __device__ ListPlan truncated_list(int32_t node, int64_t deg, int m, uint64_t h)
   return L;
 }
 
-__global__ __launch_bounds__(kSealBlock) void seal_subgraph_kernel(
+// latency-bound: 8 waves per SIMD (64 VGPRs, 6 of them spilled) beat 6 waves with none
+__global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void seal_subgraph_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_graph, const int64_t* __restrict__ pairs,
     int64_t B, int hop, int max_nb, int replay, int cap_policy, uint64_t seed, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
     int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag) {
