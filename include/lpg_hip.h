@@ -226,6 +226,11 @@ int lpg_seal_features_f32(const int32_t* nodes, const int32_t* n_nodes, const in
                           const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len,
                           int64_t T, const float* emb, int64_t emb_dim, int64_t B, float* x,
                           int64_t ldx, int zero_pad, int32_t* err_flag, void* stream);
+/* same, X stored as bfloat16 (the embedding half rounded to nearest even; configs[2]'s bf16 storage) */
+int lpg_seal_features_bf16(const int32_t* nodes, const int32_t* n_nodes, const int64_t* node_off,
+                           const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len,
+                           int64_t T, const float* emb, int64_t emb_dim, int64_t B, uint16_t* x,
+                           int64_t ldx, int zero_pad, int32_t* err_flag, void* stream);
 /* zero_pad != 0: columns [T + emb_dim, ldx) of every row are written with zeros as well.  Rows padded to a
  * 16-byte multiple are then written as whole cache lines (a row with an unwritten tail turns every store
  * of the kernel into a read-modify-write: 2x slower), and the pad is safe to feed to a GEMM. */

@@ -243,15 +243,13 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.
     emb_dim = 0 if emb is None else emb.shape[1]
     emb = None if emb is None else _ops._c(emb, torch.float32)
     width = tags_size + emb_dim
-    x = torch.empty((total, -(-width // 8) * 8), dtype=torch.float32, device=dev)[:, :width]
-    _lib.check(lib.lpg_seal_features_f32(P(batch.nodes), P(batch.n), P(off), P(batch.tags), P(tag_map),
-                                         tag_map.numel(), tags_size, P(emb), emb_dim, batch.B, P(x), x.stride(0), 1,
-                                         P(_ops.err_flag(dev)), S()), "seal_features")
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("gnn_inputs: dtype must be float32 or bfloat16")
+    x = torch.empty((total, -(-width // 8) * 8), dtype=dtype, device=dev)[:, :width]
+    fn = lib.lpg_seal_features_f32 if dtype == torch.float32 else lib.lpg_seal_features_bf16   # bf16: stored directly
+    _lib.check(fn(P(batch.nodes), P(batch.n), P(off), P(batch.tags), P(tag_map), tag_map.numel(), tags_size, P(emb),
+                  emb_dim, batch.B, P(x), x.stride(0), 1, P(_ops.err_flag(dev)), S()), "seal_features")
     _ops.maybe_check(dev, "seal feature index")
-    if dtype != torch.float32:
-        xs = torch.empty((total, -(-width // 8) * 8), dtype=dtype, device=dev)[:, :width]
-        xs.copy_(x)
-        x = xs
     return g, d_inv[:total], x
 
 

@@ -870,6 +870,9 @@ def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
     z32, k32 = seal.graph_conv_stack(g, d_inv, x, [w1] + gw[1:])
     z16, k16 = seal.graph_conv_stack(g, d_inv, x.bfloat16(), [w1.bfloat16()] + [w.bfloat16() for w in gw[1:]])
     assert z16.dtype == torch.bfloat16
+    # X stored directly in bf16 by the features kernel == the fp32 X rounded once (round to nearest even)
+    g16, _, x16 = seal.gnn_inputs(batch, tag_map, T, emb, dtype=torch.bfloat16)
+    assert x16.dtype == torch.bfloat16 and x16.stride(0) % 8 == 0 and torch.equal(x16, x.bfloat16())
     assert float((z16.float() - z32).abs().max()) < 0.03 and float((k16.float() - k32).abs().max()) < 0.03
 
 
