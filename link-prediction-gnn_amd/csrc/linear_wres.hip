@@ -90,15 +90,15 @@ __device__ __forceinline__ uint4 keep_first(uint4 v, int keep, uint16_t*) {
 // W -> LDS, once per workgroup: [NT*32 columns][KPAD + EPB], zero outside [m, k].  Batches of 8 loads
 // from clamped addresses, then the selects (written as `cond ? load : 0` hipcc branches around every
 // load and waits for each one; see linear.hip).
-template <typename T, int NT, int KPAD>
+template <typename T, int NT, int KPAD, int BLOCK = kBlock>
 __device__ __forceinline__ void stage_w(T* Ws, const T* __restrict__ w, int w_is_km, int j0, int k, int m, int tid) {
   constexpr int LD = KPAD + Elt<T>::EPB, TOTAL = NT * 32 * KPAD;
-  for (int base = 0; base < TOTAL; base += 8 * kBlock) {
+  for (int base = 0; base < TOTAL; base += 8 * BLOCK) {
     T v[8];
     int jj[8], kk[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int idx = min(base + u * kBlock + tid, TOTAL - 1);
+      const int idx = min(base + u * BLOCK + tid, TOTAL - 1);
       if (w_is_km) { kk[u] = idx / (NT * 32); jj[u] = idx % (NT * 32); }   // lanes walk m
       else { jj[u] = idx / KPAD; kk[u] = idx % KPAD; }                     // lanes walk k
       const int jc = min(j0 + jj[u], m - 1), kc = min(kk[u], k - 1);
@@ -313,13 +313,116 @@ __global__ __launch_bounds__(kBlock, 2) void linear_wres2_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Variant 3 = variant 2 with the result leaving through LDS.  Stores from the accumulator layout are 4 (2) bytes
+// per lane, 64 store instructions per 32 x 128 tile; measured on fp32 k = m = 128 they cost 0.38 of the 1.51 ms
+// although the bytes are few -- the memory pipeline is paid per instruction.  Here a wave writes half a tile
+// (16 rows) into a private LDS slice and stores it as whole 16-byte row pieces, twice: 16 instructions per tile.
+// The slices do not fit next to two W copies, so ONE 512-thread workgroup per CU shares one W (8 waves).
+constexpr int kBlock3 = 512;
+template <typename T, int NT, int PG, int ACT>
+__global__ __launch_bounds__(kBlock3, 1) void linear_wres3_kernel(
+    const T* __restrict__ x, int64_t ldx, const T* __restrict__ w, int w_is_km, const float* __restrict__ bias,
+    T* __restrict__ y, int64_t ldy, int64_t n, int k, int m, int64_t n_tiles, int y_vec) {
+  constexpr int EPB = Elt<T>::EPB, GK = Elt<T>::GK, KPAD = PG * GK, LD = KPAD + EPB;
+  constexpr int LDO = NT * 32 + EPB;               // LDS row of the half output tile
+  extern __shared__ uint4 smem_raw[];
+  T* Ws = reinterpret_cast<T*>(smem_raw);            // [NT*32][LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* Os = Ws + NT * 32 * LD + wave * 16 * LDO;       // wave-private [16][LDO]
+  const int j0 = blockIdx.y * (NT * 32);
+  const int fr = lane & 31, fk = lane >> 5;
+  stage_w<T, NT, KPAD, kBlock3>(Ws, w, w_is_km, j0, k, m, tid);
+  __syncthreads();
+
+  float bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv[t] = (bias && j0 + t * 32 + fr < m) ? bias[j0 + t * 32 + fr] : 0.f;
+  const bool kmask = k != KPAD;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kBlock3 / 64);
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * (kBlock3 / 64) + wave;
+  const int ko0 = fk * (GK / 2);
+  const T* bp = Ws + fr * LD + ko0;
+  auto row_ptr = [&](int64_t tl) {
+    int64_t r = tl * 32 + fr;
+    r = r < n ? r : n - 1;
+    return x + r * ldx;
+  };
+  uint4 xr[PG];
+  if (tile < n_tiles) {
+    const T* rp = row_ptr(tile);
+#pragma unroll
+    for (int g = 0; g < PG; ++g) xr[g] = *reinterpret_cast<const uint4*>(rp + (g * GK + ko0 < k ? g * GK + ko0 : 0));
+  }
+  for (; tile < n_tiles; tile += n_waves) {
+    const int64_t row0 = tile * 32;
+    const int64_t nx = tile + n_waves;
+    const T* rp = row_ptr(nx < n_tiles ? nx : tile);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+      uint4 a = xr[g];
+      const int ko = g * GK + ko0;
+      if (kmask) {
+        a = and4(a, k - ko > 0 ? 0xffffffffu : 0u);
+        a = keep_first(a, k - ko, static_cast<T*>(nullptr));
+      }
+      xr[g] = *reinterpret_cast<const uint4*>(rp + (ko < k ? ko : 0));
+      uint4 b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const uint4*>(bp + t * 32 * LD + g * GK);
+      mfma_groups<NT>(a, b, acc, static_cast<T*>(nullptr));
+      if (g % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int OPR = NT * 32 / EPB;               // 16-byte pieces per output row
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {           // accumulator registers 8*half .. 8*half+7 hold rows 16*half .. +15
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = t * 32 + fr;
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = half * 8 + r8;
+          const int rl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * fk;      // row inside the half tile
+          Os[rl * LDO + c] = Elt<T>::from_f32(apply_act(acc[t][r] + bv[t], ACT));
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the slice is wave-private
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < (16 * OPR) / 64; ++it) {
+        const int p = it * 64 + lane, rr = p / OPR, c = (p % OPR) * EPB;
+        const int64_t row = row0 + half * 16 + rr;
+        const int col = j0 + c;
+        if (row < n && col < m) {
+          const T* src = Os + rr * LDO + c;
+          T* dst = y + row * ldy + col;
+          if (y_vec && col + EPB <= m) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPB; ++e)
+              if (col + e < m) dst[e] = src[e];
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();               // the slice is rewritten by the next half
+    }
+  }
+}
+
 template <typename K>
-int blocks_per_cu(K kern, size_t lds) {
+int blocks_per_cu(K kern, size_t lds, int block = kBlock) {
   int b = 0;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                           160 * 1024) != hipSuccess)
     return -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, kBlock, lds) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, block, lds) != hipSuccess) return -1;
   return b < 1 ? 1 : b;
 }
 
@@ -340,8 +443,20 @@ int launch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float* b
   constexpr int EPB = Elt<T>::EPB, KPAD = PG * Elt<T>::GK, LD = KPAD + EPB, LDO = NT * 32 + EPB;
   const int64_t n_tiles = ceil_div(n, 32);
   const unsigned gy = static_cast<unsigned>(ceil_div(m, NT * 32));
-  static int per_cu[2] = {0, 0};                    // per instantiation; the occupancy query is slow
-  if (variant == 2 || PG == 20) {                   // PG = 20 (fp32, 128 < k <= 160) exists as variant 2 only
+  static int per_cu[3] = {0, 0, 0};                 // per instantiation; the occupancy query is slow
+  if constexpr (NT == 4 && PG == 16) {
+    if (variant == 3) {
+      auto kern = linear_wres3_kernel<T, NT, PG, ACT>;
+      constexpr size_t lds = (static_cast<size_t>(NT) * 32 * LD + (kBlock3 / 64) * 16 * static_cast<size_t>(LDO)) * sizeof(T);
+      if (!per_cu[2]) per_cu[2] = blocks_per_cu(kern, lds, kBlock3);
+      LPG_REQUIRE(per_cu[2] > 0, "linear (W-resident): occupancy query failed");
+      const int64_t gx = std::min<int64_t>(static_cast<int64_t>(cu_count()) * per_cu[2], ceil_div(n_tiles, kBlock3 / 64));
+      hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx), gy), dim3(kBlock3), lds, st, x, ldx, w, w_is_km, bias, y,
+                         ldy, n, k, m, n_tiles, y_vec);
+      return 1;
+    }
+  }
+  if (variant == 2 || variant == 3 || PG == 20) {                   // PG = 20 (fp32, 128 < k <= 160) exists as variant 2 only
     auto kern = linear_wres2_kernel<T, NT, PG, ACT>;
     constexpr size_t lds = static_cast<size_t>(NT) * 32 * LD * sizeof(T);
     if (!per_cu[1]) per_cu[1] = blocks_per_cu(kern, lds);
@@ -394,10 +509,10 @@ int dispatch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float*
   const int pg = k <= 4 * GK ? 4 : (k <= 8 * GK ? 8 : (k <= 16 * GK ? 16 : 20));
   if (variant < 0) {
     // measured on MI355X (profiles/r01/linear_ab.log): the MFMA-bound fp32 shapes and k > 128 bf16 want the
-    // staging-free variant 2; the HBM-bound rest wants the coalesced variant 1; bf16 [k = 128] -> [m <= 32] is
+    // staging-free variants 2 / 3 (3 = LDS-staged stores: fp32 128x128 1.60 -> 1.55 ms, bf16 256 -> 128 0.83 -> 0.74); the HBM-bound rest wants the coalesced variant 1; bf16 [k = 128] -> [m <= 32] is
     // the one shape where the tiled kernel is still ahead (0.28 vs 0.32 ms at n = 5 M)
-    if (sizeof(T) == 4) variant = nt == 4 ? 2 : 1;
-    else variant = pg == 16 ? 2 : 1;
+    if (sizeof(T) == 4) variant = nt == 4 ? (pg == 16 ? 3 : 2) : 1;
+    else variant = pg == 16 ? (nt == 4 ? 3 : 2) : 1;
     if (sizeof(T) == 2 && nt == 1 && pg == 8 && k % 8 == 0 && m % 8 == 0 && ldy % 8 == 0) return 0;
   }
   const int y_vec = ldy % EPB == 0 && al16(y);

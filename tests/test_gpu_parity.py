@@ -802,7 +802,7 @@ def test_linear_bf16_mfma(dev, n, k, m, km):
     assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + TOL * mag + 1e-30)
 
 
-@pytest.mark.parametrize("variant", ["auto", "1", "2"])
+@pytest.mark.parametrize("variant", ["auto", "1", "2", "3"])
 @pytest.mark.parametrize("dtype,n,k,m,ldx,km,act,bias", [
     ("f32", 20011, 128, 128, 128, False, None, True),       # MFMA-bound shape, ragged last tile
     ("f32", 16385, 32, 32, 32, True, "tanh", False),
