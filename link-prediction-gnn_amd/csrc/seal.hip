@@ -28,37 +28,46 @@ __device__ __forceinline__ bool row_has(const int32_t* __restrict__ row, int len
   return lo < len && row[lo] == key;
 }
 
-__device__ void bfs_bits(const uint32_t (*adj)[WORDS], int n, int src, int* dist, uint32_t* vis, uint32_t* fr,
-                         uint32_t* nx) {
+// Both BFS sweeps of the DRNL labelling (from target 0 and from target 1) advance in the SAME level loop: the
+// three barriers of a level are shared, which halves the barrier count of the labelling (it is latency, not work).
+// vis / fr / nx hold two bit sets each: [0, WORDS) for source 0, [WORDS, 2 WORDS) for source 1.
+__device__ void bfs2_bits(const uint32_t (*adj)[WORDS], int n, int* dist0, int* dist1, uint32_t* vis, uint32_t* fr,
+                          uint32_t* nx) {
   const int t = threadIdx.x;
-  if (t < MAXN) dist[t] = -1;
-  if (t < WORDS) { vis[t] = 0; fr[t] = 0; nx[t] = 0; }
+  if (t < MAXN) { dist0[t] = -1; dist1[t] = -1; }
+  if (t < 2 * WORDS) { vis[t] = 0; fr[t] = 0; nx[t] = 0; }
   __syncthreads();
   if (t == 0) {
-    dist[src] = 0;
-    vis[src >> 5] = 1u << (src & 31);
-    fr[src >> 5] = 1u << (src & 31);
+    dist0[0] = 0; vis[0] = 1u; fr[0] = 1u;                       // source 0 = vertex 0
+    dist1[1] = 0; vis[WORDS] = 2u; fr[WORDS] = 2u;               // source 1 = vertex 1
   }
   __syncthreads();
   for (int level = 1; level <= n; ++level) {      // at most n-1 productive levels
-    if (t < n && ((fr[t >> 5] >> (t & 31)) & 1u)) {
+    if (t < n) {
+      const bool f0 = (fr[t >> 5] >> (t & 31)) & 1u, f1 = (fr[WORDS + (t >> 5)] >> (t & 31)) & 1u;
+      if (f0 || f1) {
 #pragma unroll
-      for (int w = 0; w < WORDS; ++w) {
-        const uint32_t m = adj[t][w];
-        if (m) atomicOr(&nx[w], m);
+        for (int w = 0; w < WORDS; ++w) {
+          const uint32_t m = adj[t][w];
+          if (m && f0) atomicOr(&nx[w], m);
+          if (m && f1) atomicOr(&nx[WORDS + w], m);
+        }
       }
     }
     __syncthreads();
     bool any = false;
-    uint32_t fresh[WORDS];
+    uint32_t fresh[2 * WORDS];
 #pragma unroll
-    for (int w = 0; w < WORDS; ++w) {
+    for (int w = 0; w < 2 * WORDS; ++w) {
       fresh[w] = nx[w] & ~vis[w];
       any |= fresh[w] != 0;
     }
-    if (t < n && ((fresh[t >> 5] >> (t & 31)) & 1u)) dist[t] = level;
+    if (t < n) {
+      if ((fresh[t >> 5] >> (t & 31)) & 1u) dist0[t] = level;
+      if ((fresh[WORDS + (t >> 5)] >> (t & 31)) & 1u) dist1[t] = level;
+    }
     __syncthreads();
-    if (t < WORDS) { vis[t] |= fresh[t]; fr[t] = fresh[t]; nx[t] = 0; }
+    if (t < 2 * WORDS) { vis[t] |= fresh[t]; fr[t] = fresh[t]; nx[t] = 0; }
     __syncthreads();
     if (!any) break;                               // uniform: every thread computed the same `any`
   }
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
   __shared__ int32_t nodes[MAXN];
   __shared__ uint32_t adj[MAXN][WORDS];
   __shared__ int dist0[MAXN], dist1[MAXN];
-  __shared__ uint32_t vis[WORDS], fr[WORDS], nx[WORDS];
+  __shared__ uint32_t vis[2 * WORDS], fr[2 * WORDS], nx[2 * WORDS];
   __shared__ int s_n, s_capped, s_cnt[2], s_nbig;
   __shared__ ListPlan s_list[2];
   __shared__ int64_t rbase[MAXN];                  // per subgraph vertex: its neighbour list in the big graph
@@ -379,9 +388,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     __syncthreads();
 
     // ---- DRNL (utils.py:35-54): two BFS sweeps on the bit matrix
-    bfs_bits(adj, n, 0, dist0, vis, fr, nx);
-    __syncthreads();
-    bfs_bits(adj, n, 1, dist1, vis, fr, nx);
+    bfs2_bits(adj, n, dist0, dist1, vis, fr, nx);
     __syncthreads();
     if (t < MAXN) {
       int tag = -1, nd = -1;
