@@ -55,7 +55,7 @@ for n, k, m, ldx, km, dt, acti, has_b in shapes:
     b = torch.randn(m, device=dev) if has_b else None
     out = {}
     res = {}
-    for mode in ("0", "1", "2"):
+    for mode in ("0", "1", "2", "3"):
         os.environ["LPG_LINEAR_WRES"] = mode
         y = ops.linear(x, w, b, w_is_km=km, act=act)
         res[mode] = y
@@ -71,9 +71,9 @@ for n, k, m, ldx, km, dt, acti, has_b in shapes:
     same_shape = res["1"].shape == (n, m) and bool(torch.isfinite(res["1"].float()).all())
     elt = 4 if dt == torch.float32 else 2
     gb = n * (k + m) * elt / 1e9
-    best = min(out["1"], out["2"])
+    best = min(out["1"], out["2"], out["3"])
     ok = all(errs[md] < tol for md in errs) and same_shape and bool(torch.isfinite(res["2"].float()).all())
     print(f"n={n} k={k} m={m} ldx={ldx} km={int(km)} {str(dt)[6:]} act={act} bias={int(has_b)}: tiled {out['0']:.3f} "
-          f"wres1 {out['1']:.3f} wres2 {out['2']:.3f} ms (best {gb / best * 1e3:.0f} GB/s, {2 * n * k * m / best / 1e9:.1f} TF)  "
-          f"err {errs['0']:.1e} {errs['1']:.1e} {errs['2']:.1e} {'OK' if ok else 'FAIL'}", flush=True)
+          f"wres1 {out['1']:.3f} wres2 {out['2']:.3f} wres3 {out['3']:.3f} ms (best {gb / best * 1e3:.0f} GB/s, {2 * n * k * m / best / 1e9:.1f} TF)  "
+          f"err {errs['0']:.1e} {errs['1']:.1e} {errs['2']:.1e} {errs['3']:.1e} {'OK' if ok else 'FAIL'}", flush=True)
     del xb, x, w, res
