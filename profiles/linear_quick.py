@@ -14,7 +14,7 @@ def timed(fn, it=20):
     return s.elapsed_time(e) / it
 n = 5_000_000
 for dt in (torch.float32, torch.bfloat16):
-    for k, m in ((128, 128), (256, 128)):
+    for k, m in ((32, 32), (64, 64), (128, 32), (128, 128)):
         if dt == torch.float32 and k > 128: continue
         x = torch.randn((n, k), device=dev).to(dt); w = (torch.randn((m, k), device=dev) * 0.1).to(dt)
         r = []
