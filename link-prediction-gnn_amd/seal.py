@@ -296,7 +296,9 @@ def head(z, key, node_off, hw):
     B = node_off.numel() - 1
     pooled = sortpool(z, key, node_off, k)                                               # [B, k, 96]
     a = _ops.linear(pooled.view(B * k, -1), k1, w_is_km=True)                            # [B*k, 16]
-    c = torch.zeros((B * k, c2), dtype=torch.float32, device=z.device)
+    # rows t >= k - fw + 1 of a subgraph's block are windows that run into the next subgraph; the dense layer below
+    # reads only the first (k - fw + 1) * c2 values of each block, so they (and the unwritten tail) are never used
+    c = torch.empty((B * k, c2), dtype=torch.float32, device=z.device)
     _ops.linear(a, k2, w_is_km=True, n=B * k - (fw - 1), ldx=c1, out=c[: B * k - (fw - 1)])   # windows t..t+4
     dense = _ops.linear(c, hw["weight_1"], hw["bias_1"], w_is_km=True, act="relu", n=B, ldx=k * c2)
     pre_y = _ops.linear(dense, hw["weight_2"], hw["bias_2"], w_is_km=True)
