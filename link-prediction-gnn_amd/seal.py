@@ -44,11 +44,15 @@ class SubgraphBatch:
     def __init__(self, pairs, nodes, n, tags, adj_bits, capped):
         self.pairs, self.nodes, self.n, self.tags, self.adj_bits, self.capped = pairs, nodes, n, tags, adj_bits, capped
         self.B = pairs.shape[0]
+        self._off = None
 
     def node_off(self):
-        off = torch.zeros(self.B + 1, dtype=torch.int64, device=self.n.device)
-        off[1:] = torch.cumsum(self.n.to(torch.int64), 0)
-        return off
+        """exclusive prefix sum of the subgraph sizes, int64 [B+1]; computed once per batch."""
+        if self._off is None:
+            off = torch.zeros(self.B + 1, dtype=torch.int64, device=self.n.device)
+            off[1:] = torch.cumsum(self.n.to(torch.int64), 0)
+            self._off = off
+        return self._off
 
 
 CAP_POLICY = {"report": 0, "device": 1}
@@ -188,6 +192,7 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
                                     replay_n=np.asarray([len(l) for l in lists], dtype=np.int32))
             ii = torch.as_tensor(idx, device=batch.n.device)
             batch.nodes[ii], batch.n[ii], batch.tags[ii], batch.adj_bits[ii] = sub.nodes, sub.n, sub.tags, sub.adj_bits
+            batch._off = None                                  # the sizes changed
     labels = torch.cat([torch.zeros(len(negative), dtype=torch.uint8), torch.ones(len(positive), dtype=torch.uint8)])
     tag_map, tags_size = compact_tag_map(batch)
     return batch, labels.reshape(-1, 1), tags_size, tag_map, graph
