@@ -235,6 +235,19 @@ int lpg_seal_features_bf16(const int32_t* nodes, const int32_t* n_nodes, const i
  * 16-byte multiple are then written as whole cache lines (a row with an unwritten tail turns every store
  * of the kernel into a read-modify-write: 2x slower), and the pad is safe to feed to a GEMM. */
 
+/* Layers 1..4 of the reference's fixed SEAL architecture (graph weights [F,32], [32,32], [32,32], [32,1];
+ * SEAL/model/gnn.py:32-42,46-63) for a whole batch as dense 32 x 32 block products on the fp32 matrix cores,
+ * every block of D^-1 (A + I) built in registers from the bit adjacency (the reference feeds the same dense
+ * operands to tf.matmul, one subgraph per run).  Given h1 = X W_1 [total, 32] (lpg_linear_f32) it writes
+ * cat = [Z_1 | Z_2 | Z_3] [total, >= 96] and key = Z_4[:, 0] [total]; no block CSR, no plan, no intermediate
+ * in HBM.  first[w] (int32, n_windows + 1 entries) = the first subgraph whose first row is >= 128 w, i.e.
+ * lower_bound(node_off, 128 w) clamped to B, for w = 0 .. ceil(total / 128); a workgroup owns the subgraphs that
+ * start in its 128-row window.  w2, w3 are [32,32] with the INPUT index major (TensorFlow's x @ W), w4 is [32]. */
+int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
+                            const uint32_t* adj_bits, const float* h1, int64_t ldh, const float* w2,
+                            const float* w3, const float* w4, float* cat, int64_t ldc, float* key,
+                            void* stream);
+
 /* ---------------------------------------------------------------- SEAL head
  * SortPooling [SEAL/model/gnn.py:82-91]: per subgraph b, order its n_b vertices by key (= Z_4[:,0])
  * descending, ties -> lower vertex index first (tf.nn.top_k), take the first k rows of z

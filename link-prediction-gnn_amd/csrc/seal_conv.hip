@@ -1,0 +1,208 @@
+// SEAL graph convolution, layers 1..4 of the reference's fixed architecture, as DENSE block products on the
+// fp32 matrix cores (a9):  Z_l = tanh(D^-1 (A~ (Z_{l-1} W_l))), widths 32 / 32 / 32 / 1
+// (SEAL/model/gnn.py:32-42 weights, :46-63 layers).  The reference itself feeds dense [n,n] A~ and D^-1 to
+// tf.matmul, one subgraph per session run; a subgraph has <= 128 vertices and its adjacency is already a bit
+// matrix in HBM (lpg_seal_subgraphs), so the dense formulation costs nothing to build: a 32 x 32 block of
+// D^-1 A~ is materialised in registers, in the A-operand layout of v_mfma_f32_32x32x2_f32, straight from the bits.
+//
+// Work decomposition.  Vertex rows of a batch are numbered globally (subgraph b owns [node_off[b], node_off[b+1])).
+// Workgroup t owns the whole subgraphs that START in rows [128 t, 128 t + 128) -- at most 255 rows -- so that
+// every H row an aggregation needs is in the workgroup's LDS.  Rows are cut into 32-row tiles; a wave owns up to
+// two tiles.  Per layer:
+//   A. Z_I = tanh( sum_J (D^-1 A~)_{IJ} H_J ) over the column tiles J that overlap the subgraphs of row tile I
+//      (1-3 for typical subgraphs): 16 MFMAs per (I, J), the B operand read from LDS;
+//      Z_I goes to its column slice of the concat buffer (layers 1-3) or to the sort key (layer 4);
+//   B. H'_I = Z_I W_{l+1}: Z_I is turned from the accumulator layout into the A layout through a wave-private
+//      LDS slice, W_{l+1} sits in registers in the B layout; 16 MFMAs;
+//   barrier, H <- H', barrier.
+// Given H_1 = X W_1 (lpg_linear_f32: the one big matmul) nothing between layer 1 and the outputs touches HBM,
+// and the block-diagonal CSR, its plan, three SpMMs + fix-ups, three small linears and the d = 1 SpMM of the
+// generic path are not needed at all.  Summation order differs from the CSR path (a zero-padded dense product
+// in MFMA order instead of ascending neighbours): deterministic, and within 1e-6 of it.
+#include "lpg_common.hpp"
+
+namespace {
+using namespace lpg;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int MAXN = LPG_SEAL_MAXN;   // 128
+constexpr int WORDS = MAXN / 32;
+constexpr int WIN = 128;              // a workgroup owns the subgraphs that start in a 128-row window
+constexpr int RMAX = WIN + MAXN;      // rows it can end up with (<= 255), rounded to tiles of 32
+constexpr int kConvBlock = 256;       // 4 waves, up to two 32-row tiles each (a workgroup has at most 8)
+
+// tanh(v) = 1 - 2 / (exp(2 v) + 1) with the hardware reciprocal (1 ulp): |error| < 3e-7 absolute on an output in
+// [-1, 1], branch-free; saturates cleanly (exp -> inf gives 1, exp -> 0 gives -1).
+__device__ __forceinline__ float tanh_fast_div(float v) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f); }
+
+struct RowCtx {
+  int q, i, start;     // local subgraph index (-1: no row), vertex index inside it, the subgraph's first local row
+  float one;           // D^-1 of the row
+  bool self;           // A[i][i] set
+  uint32_t b0, b1, b2, b3;   // the row's adjacency bits
+};
+
+__global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
+    const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
+    const float* __restrict__ h1, int64_t ldh, const float* __restrict__ w2, const float* __restrict__ w3,
+    const float* __restrict__ w4, float* __restrict__ cat, int64_t ldc, float* __restrict__ key) {
+  __shared__ float H[RMAX][32];                     // 32 KB: the current layer's H rows of the owned subgraphs
+  __shared__ uint32_t rinfo[RMAX];                  // per local row: (local subgraph index << 8) | vertex index
+  __shared__ uint32_t rbits[RMAX][WORDS];           // its adjacency row
+  __shared__ int soff[WIN + 2];                     // local row offset of each owned subgraph
+  __shared__ float Zt[kConvBlock / 64][32][33];     // wave-private transposition slice
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bf = first[blockIdx.x], bl = first[blockIdx.x + 1];
+  if (bl <= bf) return;                             // a window inside one big subgraph owns nothing
+  const int nsub = bl - bf;                         // <= 128: every owned subgraph starts in the window
+  const int64_t r_lo = node_off[bf];
+  const int nrows = static_cast<int>(node_off[bl] - r_lo);
+
+  // ---- per-subgraph offsets, per-row (subgraph, vertex) and adjacency rows
+  for (int q = tid; q <= nsub; q += kConvBlock) soff[q] = static_cast<int>(node_off[bf + q] - r_lo);
+  __syncthreads();
+  for (int q = tid; q < nsub; q += kConvBlock)
+    for (int lr = soff[q]; lr < soff[q + 1]; ++lr) rinfo[lr] = (static_cast<uint32_t>(q) << 8) | static_cast<uint32_t>(lr - soff[q]);
+  __syncthreads();
+  for (int lr = tid; lr < nrows; lr += kConvBlock) {
+    const uint32_t ri = rinfo[lr];
+    const uint4 q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + (ri >> 8)) * MAXN + (ri & 255u)) * WORDS);
+    rbits[lr][0] = q4.x; rbits[lr][1] = q4.y; rbits[lr][2] = q4.z; rbits[lr][3] = q4.w;
+  }
+  for (int idx = tid; idx < nrows * 32; idx += kConvBlock) H[idx >> 5][idx & 31] = h1[(r_lo + (idx >> 5)) * ldh + (idx & 31)];
+  // W_{l+1} in the B-operand layout: lane (n = r, h) holds W[k = 2 s + h][n] for s = 0..15
+  float Wb2[16], Wb3[16], Wb4[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    Wb2[s] = w2[(2 * s + h) * 32 + r];
+    Wb3[s] = w3[(2 * s + h) * 32 + r];
+    Wb4[s] = r == 0 ? w4[2 * s + h] : 0.f;          // 32 -> 1 as a 32 x 32 product whose column 0 is the result
+  }
+  __syncthreads();
+
+  const int ntiles = (nrows + 31) >> 5;             // <= 8
+  // my (up to two) row tiles: per lane the row lr = 32 I + r it feeds into the A operand.  (Named scalars, not
+  // arrays: indexed by the tile loop they ended up in scratch memory, one scratch load per MFMA step.)
+  auto row_ctx = [&](int I) {
+    RowCtx c{-1, -100000, 0, 0.f, false, 0u, 0u, 0u, 0u};
+    const int lr = 32 * I + r;
+    if (I < ntiles && lr < nrows) {
+      const uint32_t ri = rinfo[lr];
+      c.q = static_cast<int>(ri >> 8);
+      c.i = static_cast<int>(ri & 255u);
+      c.start = soff[c.q];
+      c.b0 = rbits[lr][0]; c.b1 = rbits[lr][1]; c.b2 = rbits[lr][2]; c.b3 = rbits[lr][3];
+      const int pc = __popc(c.b0) + __popc(c.b1) + __popc(c.b2) + __popc(c.b3);
+      c.one = static_cast<float>(1.0 / static_cast<double>(pc + 1));             // D^-1 = 1 / rowsum(A + I)
+      const uint32_t wi = c.i < 32 ? c.b0 : (c.i < 64 ? c.b1 : (c.i < 96 ? c.b2 : c.b3));
+      c.self = (wi >> (c.i & 31)) & 1u;
+    }
+    return c;
+  };
+  const RowCtx ctx0 = row_ctx(wave), ctx1 = row_ctx(wave + kConvBlock / 64);
+
+  // sum_J (D^-1 (A + I))_{IJ} H_J for row tile I, then tanh; returns Z in the accumulator layout
+  auto aggregate = [&](int I, const RowCtx& cx) {
+    const int lr0 = 32 * I, lr1 = min(32 * I + 31, nrows - 1);
+    const int c_lo = soff[rinfo[lr0] >> 8], c_hi = soff[(rinfo[lr1] >> 8) + 1];   // columns of the subgraphs it overlaps
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int J = c_lo >> 5; J <= (c_hi - 1) >> 5; ++J) {
+      // The columns of tile J that belong to my row's subgraph are a contiguous run of its vertices: column c' is
+      // vertex p0 + c'.  So the 32 entries of (A + I)[my row][tile J] are a 32-bit WINDOW of my 128-bit adjacency
+      // row starting at bit p0 (zero outside the subgraph), plus the diagonal: one funnel shift per block.  (A
+      // column-info lookup and a word select per step were 30 VALU instructions per MFMA; kept in arrays indexed by
+      // the tile loop they even went to scratch memory, one scratch load per step.)
+      const int p0 = 32 * J - cx.start;
+      const int w = p0 >> 5, sh = p0 & 31;           // arithmetic shift: p0 may be negative
+      auto word = [&](int k) { return k == 0 ? cx.b0 : (k == 1 ? cx.b1 : (k == 2 ? cx.b2 : (k == 3 ? cx.b3 : 0u))); };
+      const uint32_t lo = word(w), hi = word(w + 1);
+      uint32_t win = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+      if (cx.q < 0) win = 0u;
+      const uint32_t winh = win >> h;                // this lane supplies columns c' = 2 s + h
+      const int cdh = cx.i - p0 - h;                 // the diagonal sits at step s = cdh / 2 when cdh is even and in range
+      const float dval = cx.self ? 2.f * cx.one : cx.one;
+      float bvals[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int lc = 32 * J + 2 * s + h;           // the column (= local row of H) this lane supplies
+        bvals[s] = H[lc < nrows ? lc : 0][r];        // (rows past the end may hold anything; their A entries are 0)
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        float a = ((winh >> (2 * s)) & 1u) ? cx.one : 0.f;
+        a = cdh == 2 * s ? dval : a;                 // + I (a self loop in A makes it 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvals[s], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = tanh_fast_div(acc[i]);
+    return acc;
+  };
+
+#pragma unroll 1
+  for (int layer = 1; layer <= 4; ++layer) {
+    f32x16 hn0, hn1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int I = wave + t * (kConvBlock / 64);
+      if (I >= ntiles) continue;                     // wave-uniform
+      const f32x16 z = aggregate(I, t == 0 ? ctx0 : ctx1);
+      // accumulator layout: column = r (feature), row = (reg & 3) + 8 (reg >> 2) + 4 h
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int lr = 32 * I + row;
+        if (lr < nrows) {
+          if (layer < 4) cat[(r_lo + lr) * ldc + (layer - 1) * 32 + r] = z[i];
+          else if (r == 0) key[r_lo + lr] = z[i];
+        }
+        Zt[wave][row][r] = z[i];
+      }
+      if (layer == 4) continue;
+      __builtin_amdgcn_s_waitcnt(0xC07F);            // the slice is wave-private
+      __builtin_amdgcn_wave_barrier();
+      float za[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) za[s] = Zt[wave][r][2 * s + h];   // A layout: lane (row r, half h) supplies Z[r][2 s + h]
+      asm volatile("" ::: "memory");
+      f32x16 hn;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hn[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float bv = layer == 1 ? Wb2[s] : (layer == 2 ? Wb3[s] : Wb4[s]);
+        hn = __builtin_amdgcn_mfma_f32_32x32x2f32(za[s], bv, hn, 0, 0, 0);
+      }
+      if (t == 0) hn0 = hn; else hn1 = hn;
+      __builtin_amdgcn_wave_barrier();               // Zt is rewritten by the wave's next tile
+    }
+    if (layer == 4) break;
+    __syncthreads();                                 // every aggregation of this layer has read H
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int I = wave + t * (kConvBlock / 64);
+      if (I >= ntiles) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) H[32 * I + (i & 3) + 8 * (i >> 2) + 4 * h][r] = t == 0 ? hn0[i] : hn1[i];
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+LPG_EXPORT int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
+                                       const uint32_t* adj_bits, const float* h1, int64_t ldh, const float* w2,
+                                       const float* w3, const float* w4, float* cat, int64_t ldc, float* key,
+                                       void* stream) {
+  LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && ldh >= 32 && ldc >= 96, "seal_conv_stack: bad sizes");
+  if (n_windows == 0) return LPG_OK;
+  LPG_REQUIRE(node_off && first && adj_bits && h1 && w2 && w3 && w4 && cat && key, "seal_conv_stack: null pointer");
+  hipLaunchKernelGGL(seal_conv_dense_kernel, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0, as_stream(stream),
+                     node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key);
+  return check_launch("seal_conv_stack");
+}

@@ -10,6 +10,8 @@ dense [n,n] operands).  Here a whole batch of candidates is one launch per stage
 extracted and labelled on the device, stacked into ONE block-diagonal CSR, and each of the four
 graph-conv layers is one MFMA linear + one fused SpMM (row scale D^-1 and tanh in the epilogue).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -217,17 +219,41 @@ def compact_tag_map(batch):
     return tag_map, T
 
 
-def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.float32):
+def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.float32, build_csr=True):
     """SEAL/config/data.py:94-140 batched: block-diagonal A~ = A + I (CSR, values 1 / 2),
     D^-1 = 1/rowsum(A~) per vertex, X = [onehot(tag) || emb[node]].  Returns (CSRGraph, d_inv, X).
     fold_dinv (default): the CSR values are D^-1 A~, so graph_conv_stack needs no per-row scale in the
     SpMM epilogue (a load at a row flush drains the gathers in flight); d_inv is still returned.
     X's rows are padded to a multiple of 16 bytes (a [total, T + dim] VIEW of a wider buffer), which is
-    what lets the first linear read them as 16-byte pieces; dtype=torch.bfloat16 stores X in bf16."""
+    what lets the first linear read them as 16-byte pieces; dtype=torch.bfloat16 stores X in bf16.
+    build_csr=False: only X is built (returns (None, None, X)) -- the dense conv stack
+    (graph_conv_stack(..., batch=batch)) works from the bit adjacency and needs no CSR."""
     lib = _lib.load()
     dev = batch.n.device
     off = batch.node_off()
     total = int(off[-1].item())
+    P, S = _ops._ptr, _ops._stream
+    if not build_csr:
+        g, d_inv = None, None
+    else:
+        g, d_inv = _block_csr(lib, batch, off, total, fold_dinv)
+        d_inv = d_inv[:total]
+    emb_dim = 0 if emb is None else emb.shape[1]
+    emb = None if emb is None else _ops._c(emb, torch.float32)
+    width = tags_size + emb_dim
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("gnn_inputs: dtype must be float32 or bfloat16")
+    x = torch.empty((total, -(-width // 8) * 8), dtype=dtype, device=dev)[:, :width]
+    fn = lib.lpg_seal_features_f32 if dtype == torch.float32 else lib.lpg_seal_features_bf16   # bf16: stored directly
+    _lib.check(fn(P(batch.nodes), P(batch.n), P(off), P(batch.tags), P(tag_map), tag_map.numel(), tags_size, P(emb),
+                  emb_dim, batch.B, P(x), x.stride(0), 1, P(_ops.err_flag(dev)), S()), "seal_features")
+    _ops.maybe_check(dev, "seal feature index")
+    return g, d_inv, x
+
+
+def _block_csr(lib, batch, off, total, fold_dinv):
+    """block-diagonal CSR of A~ = A + I with its SpMM plan, and D^-1 (the generic aggregation path)."""
+    dev = batch.n.device
     nbytes = _lib.check(lib.lpg_seal_block_csr_bytes(total), "seal_block_csr_bytes")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rowptr = torch.empty(total + 1, dtype=torch.int64, device=dev)
@@ -245,22 +271,41 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.
     g.n_empty = 0                       # A~ = A + I: every row holds its diagonal
     g.max_row = 129                     # <= LPG_SEAL_MAXN neighbours + the diagonal (known without a sync)
     g.rows_prescaled = bool(fold_dinv)
-    emb_dim = 0 if emb is None else emb.shape[1]
-    emb = None if emb is None else _ops._c(emb, torch.float32)
-    width = tags_size + emb_dim
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError("gnn_inputs: dtype must be float32 or bfloat16")
-    x = torch.empty((total, -(-width // 8) * 8), dtype=dtype, device=dev)[:, :width]
-    fn = lib.lpg_seal_features_f32 if dtype == torch.float32 else lib.lpg_seal_features_bf16   # bf16: stored directly
-    _lib.check(fn(P(batch.nodes), P(batch.n), P(off), P(batch.tags), P(tag_map), tag_map.numel(), tags_size, P(emb),
-                  emb_dim, batch.B, P(x), x.stride(0), 1, P(_ops.err_flag(dev)), S()), "seal_features")
-    _ops.maybe_check(dev, "seal feature index")
-    return g, d_inv[:total], x
+    return g, d_inv
 
 
-def graph_conv_stack(g, d_inv, x, weights):
+def _dense_ok(weights, dtype=torch.float32):
+    """the reference's fp32 architecture: graph weights [F,32], [32,32], [32,32], [32,1] (SEAL/model/gnn.py:32-42)"""
+    return (dtype == torch.float32 and len(weights) == 4 and [tuple(w.shape)[1] for w in weights] == [32, 32, 32, 1]
+            and [tuple(w.shape)[0] for w in weights[1:]] == [32, 32, 32] and all(w.dtype == torch.float32 for w in weights)
+            and os.environ.get("LPG_SEAL_DENSE", "1") != "0")
+
+
+def graph_conv_stack(g, d_inv, x, weights, batch=None):
     """SEAL/model/gnn.py:46-63: Z_l = tanh(D^-1 (A~ (Z_{l-1} W_l))), l = 1..4.
-    Returns (concat(Z1, Z2, Z3) [total, 96], Z4[:, 0] -- the SortPooling key, :82)."""
+    Returns (concat(Z1, Z2, Z3) [total, 96], Z4[:, 0] -- the SortPooling key, :82).
+    With `batch` (the SubgraphBatch) and the reference's fp32 architecture (widths 32/32/32/1) layers 1..4 run as
+    dense 32 x 32 block products on the matrix cores straight from the bit adjacency
+    (lpg_seal_conv_stack_f32; g / d_inv may then be None); otherwise the generic path:
+    4 x (linear + block-diagonal CSR SpMM with the fused tanh epilogue)."""
+    if batch is not None and _dense_ok(weights, x.dtype):
+        lib = _lib.load()
+        h1 = _ops.linear(x, weights[0], w_is_km=True)               # the one big matmul: X W_1
+        total = x.shape[0]
+        off = batch.node_off()
+        n_win = -(-total // 128)
+        first = torch.searchsorted(off, torch.arange(n_win + 1, device=x.device, dtype=torch.int64) * 128)
+        first = first.clamp_(max=batch.B).to(torch.int32)
+        cat = torch.empty((total, 96), dtype=torch.float32, device=x.device)
+        key = torch.empty(total, dtype=torch.float32, device=x.device)
+        w2, w3, w4 = (_ops._c(w, torch.float32) for w in weights[1:])
+        P = _ops._ptr
+        _lib.check(lib.lpg_seal_conv_stack_f32(P(off), P(first), n_win, P(batch.adj_bits), P(h1), h1.stride(0), P(w2),
+                                               P(w3), P(w4), P(cat), cat.stride(0), P(key), _ops._stream()),
+                   "seal_conv_stack")
+        return cat, key
+    if g is None:
+        raise ValueError("graph_conv_stack: the generic path needs the block CSR (gnn_inputs(build_csr=True))")
     widths = [w.shape[1] for w in weights]
     cat = torch.empty((x.shape[0], sum(widths[:-1])), dtype=x.dtype, device=x.device)   # concat(Z1..Z3), written in place
     z, c0 = x, 0
@@ -316,7 +361,7 @@ def score_links(positive, negative, nodes_size, emb, weights, head_weights, test
     """the SEAL scoring forward end to end for a candidate set: structure (a10-a12), graph
     convolutions (a9) and the head.  Returns (scores [B], labels [B,1], batch)."""
     batch, labels, T, tag_map, _ = link2subgraph(positive, negative, nodes_size, test_ratio, hop, device=device)
-    g, d_inv, x = gnn_inputs(batch, tag_map, T, emb)
-    z, key = graph_conv_stack(g, d_inv, x, weights)
+    g, d_inv, x = gnn_inputs(batch, tag_map, T, emb, build_csr=not _dense_ok(weights))
+    z, key = graph_conv_stack(g, d_inv, x, weights, batch=batch)
     _, score = head(z, key, batch.node_off(), head_weights)
     return score, labels, batch

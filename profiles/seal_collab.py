@@ -33,7 +33,7 @@ BF16 = "--bf16" in sys.argv          # configs[2] says bf16: features, weights a
 def run():
     batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0)
     tag_map, T = seal.compact_tag_map(batch)
-    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb, dtype=torch.bfloat16 if BF16 else torch.float32)
+    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb, dtype=torch.bfloat16 if BF16 else torch.float32, build_csr=BF16)
     return batch, T, g, d_inv, x
 
 
@@ -54,7 +54,7 @@ def score():
         z, key = seal.graph_conv_stack(g, d_inv, x, gw16)
         z, key = z.float(), key.float()
     else:
-        z, key = seal.graph_conv_stack(g, d_inv, x, gw)
+        z, key = seal.graph_conv_stack(g, d_inv, x, gw, batch=batch)      # dense-block MFMA stack, no CSR
     return seal.head(z, key, batch.node_off(), hw)[1], batch, g
 
 

@@ -21,17 +21,18 @@ t_ext, batch = T(lambda: seal.extract_subgraphs(pairs, graph, 1, cap_policy="dev
 t_map, (tag_map, Tn) = T(lambda: seal.compact_tag_map(batch))
 BF16 = "--bf16" in sys.argv
 DT = torch.bfloat16 if BF16 else torch.float32
-t_in, (g, d_inv, x) = T(lambda: seal.gnn_inputs(batch, tag_map, Tn, emb, dtype=DT))
+GENERIC = "--generic" in sys.argv or BF16        # bf16 storage has no dense-block kernel
+t_in, (g, d_inv, x) = T(lambda: seal.gnn_inputs(batch, tag_map, Tn, emb, dtype=DT, build_csr=GENERIC))
 torch.manual_seed(0)
 gw = [torch.randn(a, b, device=dev) * 0.1 for a, b in ((Tn + D, 32), (32, 32), (32, 32), (32, 1))]
 hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, device=dev) * 0.1, "conv1d_kernel_2": torch.randn(5, 16, 32, device=dev) * 0.1,
       "weight_1": torch.randn((k - 4) * 32, 128, device=dev) * 0.1, "bias_1": torch.zeros(128, device=dev),
       "weight_2": torch.randn(128, 2, device=dev), "bias_2": torch.zeros(2, device=dev)}
 gw = [w.to(DT) for w in gw]
-t_conv, (z, key) = T(lambda: seal.graph_conv_stack(g, d_inv, x, gw))
+t_conv, (z, key) = T(lambda: seal.graph_conv_stack(g, d_inv, x, gw, batch=None if GENERIC else batch))
 z, key = z.float(), key.float()
 off = batch.node_off()
 t_head, _ = T(lambda: seal.head(z, key, off, hw))
 t_off, _ = T(lambda: batch.node_off())
 print(("bf16 " if BF16 else "fp32 ") + f"extract {t_ext:.3f}  tag_map {t_map:.3f}  gnn_inputs {t_in:.3f}  conv_stack {t_conv:.3f}  head {t_head:.3f}  (node_off {t_off:.3f}) ms; "
-      f"total vertices {int(batch.n.sum())}, nnz {g.nnz()}")
+      f"total vertices {int(batch.n.sum())}" + (f", nnz {g.nnz()}" if g is not None else ", dense conv stack"))

@@ -480,9 +480,11 @@ def test_seal_subgraphs_golden(dev, sl, hop):
             assert zlib.crc32(np.packbits(a.reshape(-1)).tobytes()) == int(sl[k + "adj_crc_canon"][g]), g
 
 
-def test_seal_graph_conv_with_reference_weights(dev, sl, golden_dir):
-    """a9 + a12: batched block-diagonal SpMM stack with the shipped checkpoint's weights against
-    the per-subgraph dense fp64 restatement of SEAL/model/gnn.py:46-63."""
+@pytest.mark.parametrize("path", ["generic", "dense"])
+def test_seal_graph_conv_with_reference_weights(dev, sl, golden_dir, path):
+    """a9 + a12: the four graph-conv layers with the shipped checkpoint's weights against the per-subgraph dense
+    fp64 restatement of SEAL/model/gnn.py:46-63 -- through the generic path (block-diagonal CSR + 4 x (linear +
+    SpMM)) and through the dense-block MFMA kernel that works from the bit adjacency (no CSR at all)."""
     from lpgnn_amd import seal
     from oracle import aggregation as agg, seal_int
     wz = np.load(os.path.join(golden_dir, "seal_weights.npz"))
@@ -492,8 +494,20 @@ def test_seal_graph_conv_with_reference_weights(dev, sl, golden_dir):
     emb = rng.standard_normal((620, 100)).astype(np.float32)         # gensim absent: seeded stand-in features
     batch, labels, T, tag_map, graph = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev)
     assert T == 6 and labels.shape == (4202, 1)
-    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, torch.from_numpy(emb).to(dev))
-    z, key = seal.graph_conv_stack(g, d_inv, x, [torch.from_numpy(w).to(dev) for w in weights])
+    wt = [torch.from_numpy(w).to(dev) for w in weights]
+    if path == "generic":
+        g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, torch.from_numpy(emb).to(dev))
+        z, key = seal.graph_conv_stack(g, d_inv, x, wt)
+    else:
+        g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, torch.from_numpy(emb).to(dev), build_csr=False)
+        assert g is None and d_inv is None
+        z, key = seal.graph_conv_stack(None, None, x, wt, batch=batch)
+        assert z.shape == (x.shape[0], 96) and key.shape == (x.shape[0],)
+        z2, key2 = seal.graph_conv_stack(None, None, x, wt, batch=batch)
+        assert torch.equal(z, z2) and torch.equal(key, key2)                 # reproducible
+        gg, dd, _ = seal.gnn_inputs(batch, tag_map, T, torch.from_numpy(emb).to(dev))
+        zg, kg = seal.graph_conv_stack(gg, dd, x, wt)                        # the two device paths agree closely
+        assert float((z - zg).abs().max()) < 1e-5 and float((key - kg).abs().max()) < 1e-5
     off = _np(batch.node_off())
     z, key, xh = _np(z).astype(np.float64), _np(key).astype(np.float64), _np(x)
     n, nodes, tags, bits = _np(batch.n), _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits)
@@ -607,6 +621,30 @@ def test_seal_auto_hop_matches_reference(dev, sl):
     assert T == 6
 
 
+def test_seal_dense_conv_stack_matches_generic_at_scale(dev):
+    """the dense-block MFMA conv stack against the generic CSR path on a hub-rich synthetic batch (236 K-node RMAT
+    graph, 20 K candidate pairs, subgraphs of 2..100 vertices incl. capped ones, max_neighbors = 128 as well):
+    every row of [Z1 | Z2 | Z3] and of the sort key within 2e-5."""
+    import bench
+    from lpgnn_amd import seal
+    N, E = 235_868, 1_285_465
+    ei = bench.rmat_edges(N, E, 1, dev)
+    graph = seal.build_train_csr(ei.t().cpu().numpy(), N, test_ratio=0.0, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4)
+    pairs = torch.randint(0, N, (20_000, 2), generator=gen, device=dev)
+    emb = torch.randn((N, 26), generator=gen, device=dev)
+    gw = [torch.randn(a, b, generator=gen, device=dev) * s for a, b, s in ((32, 32, 0.3), (32, 32, 0.4), (32, 32, 0.4), (32, 1, 0.5))]
+    for cap in (100, 128):
+        batch = seal.extract_subgraphs(pairs, graph, 1, max_neighbors=cap, cap_policy="device", seed=1)
+        tag_map, T = seal.compact_tag_map(batch)
+        assert T + 26 == 32 and int(batch.n.max()) == cap          # X is [onehot(6) || 26] = 32 wide here
+        g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb)
+        zg, kg = seal.graph_conv_stack(g, d_inv, x, gw)
+        zd, kd = seal.graph_conv_stack(None, None, x, gw, batch=batch)
+        assert zd.shape == zg.shape and float((zd - zg).abs().max()) < 2e-5 and float((kd - kg).abs().max()) < 2e-5
+
+
 def test_seal_head_with_reference_weights(dev, sl, golden_dir):
     """SortPooling + conv1d x2 + dense x2 + softmax, batched, with the shipped checkpoint's head
     weights, against the per-subgraph fp64 restatement (TensorFlow absent: parity unpinned)."""
@@ -619,8 +657,8 @@ def test_seal_head_with_reference_weights(dev, sl, golden_dir):
     pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
     emb = torch.from_numpy(np.random.default_rng(0).standard_normal((620, 100)).astype(np.float32)).to(dev)
     batch, labels, T, tag_map, _ = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev)
-    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb)
-    z, key = seal.graph_conv_stack(g, d_inv, x, gw)
+    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb, build_csr=False)      # the path score_links takes
+    z, key = seal.graph_conv_stack(g, d_inv, x, gw, batch=batch)
     pre_y, score = seal.head(z, key, batch.node_off(), hw)
     assert pre_y.shape == (4202, 2) and score.shape == (4202,)
     off = _np(batch.node_off())
