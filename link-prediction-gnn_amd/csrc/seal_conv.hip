@@ -60,6 +60,16 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
   const int64_t r_lo = node_off[bf];
   const int nrows = static_cast<int>(node_off[bl] - r_lo);
 
+  // the loads that depend on nothing but the window come first: they fly during the index work below
+  // W_{l+1} in the B-operand layout: lane (n = r, h) holds W[k = 2 s + h][n] for s = 0..15
+  float Wb2[16], Wb3[16], Wb4[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    Wb2[s] = w2[(2 * s + h) * 32 + r];
+    Wb3[s] = w3[(2 * s + h) * 32 + r];
+    Wb4[s] = r == 0 ? w4[2 * s + h] : 0.f;          // 32 -> 1 as a 32 x 32 product whose column 0 is the result
+  }
+  for (int idx = tid; idx < nrows * 32; idx += kConvBlock) H[idx >> 5][idx & 31] = h1[(r_lo + (idx >> 5)) * ldh + (idx & 31)];
   // ---- per-subgraph offsets, per-row (subgraph, vertex) and adjacency rows
   for (int q = tid; q <= nsub; q += kConvBlock) soff[q] = static_cast<int>(node_off[bf + q] - r_lo);
   __syncthreads();
@@ -70,15 +80,6 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
     const uint32_t ri = rinfo[lr];
     const uint4 q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + (ri >> 8)) * MAXN + (ri & 255u)) * WORDS);
     rbits[lr][0] = q4.x; rbits[lr][1] = q4.y; rbits[lr][2] = q4.z; rbits[lr][3] = q4.w;
-  }
-  for (int idx = tid; idx < nrows * 32; idx += kConvBlock) H[idx >> 5][idx & 31] = h1[(r_lo + (idx >> 5)) * ldh + (idx & 31)];
-  // W_{l+1} in the B-operand layout: lane (n = r, h) holds W[k = 2 s + h][n] for s = 0..15
-  float Wb2[16], Wb3[16], Wb4[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    Wb2[s] = w2[(2 * s + h) * 32 + r];
-    Wb3[s] = w3[(2 * s + h) * 32 + r];
-    Wb4[s] = r == 0 ? w4[2 * s + h] : 0.f;          // 32 -> 1 as a 32 x 32 product whose column 0 is the result
   }
   __syncthreads();
 
