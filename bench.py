@@ -192,8 +192,8 @@ def seal_forward_bench(device, iters=10):
         return seal.link2subgraph(pos, neg, 620, 0.1, 1, device=device)
 
     def aggregate(batch, tag_map, T):
-        g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb, build_csr=False)      # dense conv stack: no block CSR
-        zc, key = seal.graph_conv_stack(g, d_inv, x, weights, batch=batch)
+        h1 = seal.first_layer_h1(batch, tag_map, T, emb, weights[0])               # X W_1 from two row gathers, X never built
+        zc, key = seal.graph_conv_stack(None, None, None, weights, batch=batch, h1=h1)    # dense-block stack, no CSR
         return seal.head(zc, key, batch.node_off(), hw)[1]       # P(link) per candidate
 
     batch, _, T, tag_map, _ = structure()
@@ -246,8 +246,8 @@ def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5
 
     def score_fn(p):
         batch = seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=0)
-        g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb, build_csr=False)      # dense conv stack: no block CSR
-        z, key = seal.graph_conv_stack(g, d_inv, x, gw, batch=batch)
+        h1 = seal.first_layer_h1(batch, tag_map, T, emb, gw[0])                    # X W_1 from two row gathers, X never built
+        z, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1)          # dense-block stack, no CSR
         return seal.head(z, key, batch.node_off(), hw)[1]
 
     # No collective in here: a rank that fails must not leave the others hanging at a barrier and take the

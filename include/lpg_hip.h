@@ -234,6 +234,14 @@ int lpg_seal_features_bf16(const int32_t* nodes, const int32_t* n_nodes, const i
 /* zero_pad != 0: columns [T + emb_dim, ldx) of every row are written with zeros as well.  Rows padded to a
  * 16-byte multiple are then written as whole cache lines (a row with an unwritten tail turns every store
  * of the kernel into a read-modify-write: 2x slower), and the pad is safe to feed to a GEMM. */
+/* Layer 1 of the SEAL stack without materialising X: H_1 = X W_1 with X = [onehot(tag) || emb[node]]
+ * [SEAL/config/data.py:129-140, SEAL/model/gnn.py:46] is  H_1[g] = W_1[tag_g, :] + (emb W_1[T:, :])[node_g, :].
+ * w1_tag = the first T rows of W_1 ([T,32], input index major), p_table = emb @ W_1[T:] ([n_graph,32], one small
+ * lpg_linear_f32); both 16-byte aligned, 32 columns (the reference's layer width).  h1 [total, ldh >= 32]. */
+int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_off, const int32_t* tags,
+                           const int32_t* tag_map, int64_t tag_map_len, int64_t T, const float* w1_tag,
+                           const float* p_table, int64_t n_graph, int64_t B, float* h1, int64_t ldh,
+                           int32_t* err_flag, void* stream);
 
 /* Layers 1..4 of the reference's fixed SEAL architecture (graph weights [F,32], [32,32], [32,32], [32,1];
  * SEAL/model/gnn.py:32-42,46-63) for a whole batch as dense 32 x 32 block products on the fp32 matrix cores,

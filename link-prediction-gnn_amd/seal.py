@@ -47,6 +47,13 @@ class SubgraphBatch:
         self.pairs, self.nodes, self.n, self.tags, self.adj_bits, self.capped = pairs, nodes, n, tags, adj_bits, capped
         self.B = pairs.shape[0]
         self._off = None
+        self._total = None
+
+    def total(self):
+        """number of vertices in the batch (one host sync, cached)."""
+        if self._total is None:
+            self._total = int(self.node_off()[-1].item())
+        return self._total
 
     def node_off(self):
         """exclusive prefix sum of the subgraph sizes, int64 [B+1]; computed once per batch."""
@@ -194,7 +201,7 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
                                     replay_n=np.asarray([len(l) for l in lists], dtype=np.int32))
             ii = torch.as_tensor(idx, device=batch.n.device)
             batch.nodes[ii], batch.n[ii], batch.tags[ii], batch.adj_bits[ii] = sub.nodes, sub.n, sub.tags, sub.adj_bits
-            batch._off = None                                  # the sizes changed
+            batch._off = batch._total = None                   # the sizes changed
     labels = torch.cat([torch.zeros(len(negative), dtype=torch.uint8), torch.ones(len(positive), dtype=torch.uint8)])
     tag_map, tags_size = compact_tag_map(batch)
     return batch, labels.reshape(-1, 1), tags_size, tag_map, graph
@@ -231,7 +238,7 @@ def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.
     lib = _lib.load()
     dev = batch.n.device
     off = batch.node_off()
-    total = int(off[-1].item())
+    total = batch.total()
     P, S = _ops._ptr, _ops._stream
     if not build_csr:
         g, d_inv = None, None
@@ -274,6 +281,29 @@ def _block_csr(lib, batch, off, total, fold_dinv):
     return g, d_inv
 
 
+def first_layer_h1(batch, tag_map, tags_size, emb, w1):
+    """H_1 = X W_1 for X = [onehot(tag) || emb[node]] WITHOUT building X (SEAL/config/data.py:129-140 +
+    SEAL/model/gnn.py:46): a one-hot row times W_1 is a row of W_1, and emb[node] @ W_1[T:] is row `node` of
+    P = emb @ W_1[T:] (one small matmul), so H_1[g] = W_1[tag_g] + P[node_g].  fp32, W_1 [T + dim, 32]."""
+    lib = _lib.load()
+    T = int(tags_size)
+    w1 = _ops._c(w1, torch.float32)
+    emb = _ops._c(emb, torch.float32)
+    if w1.shape[1] != 32 or w1.shape[0] != T + emb.shape[1]:
+        raise ValueError(f"first_layer_h1: W_1 must be [{T + emb.shape[1]}, 32], got {tuple(w1.shape)}")
+    w1_tag = w1[:T].contiguous()
+    p_table = _ops.linear(emb, w1[T:], w_is_km=True)                    # [n_graph, 32]
+    off = batch.node_off()
+    total = batch.total()
+    h1 = torch.empty((total, 32), dtype=torch.float32, device=emb.device)
+    P = _ops._ptr
+    _lib.check(lib.lpg_seal_h1_tables_f32(P(batch.nodes), P(off), P(batch.tags), P(tag_map), tag_map.numel(), T,
+                                          P(w1_tag), P(p_table), emb.shape[0], batch.B, P(h1), h1.stride(0),
+                                          P(_ops.err_flag(emb.device)), _ops._stream()), "seal_h1_tables")
+    _ops.maybe_check(emb.device, "seal first-layer index")
+    return h1
+
+
 def _dense_ok(weights, dtype=torch.float32):
     """the reference's fp32 architecture: graph weights [F,32], [32,32], [32,32], [32,1] (SEAL/model/gnn.py:32-42)"""
     return (dtype == torch.float32 and len(weights) == 4 and [tuple(w.shape)[1] for w in weights] == [32, 32, 32, 1]
@@ -281,23 +311,25 @@ def _dense_ok(weights, dtype=torch.float32):
             and os.environ.get("LPG_SEAL_DENSE", "1") != "0")
 
 
-def graph_conv_stack(g, d_inv, x, weights, batch=None):
+def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None):
     """SEAL/model/gnn.py:46-63: Z_l = tanh(D^-1 (A~ (Z_{l-1} W_l))), l = 1..4.
     Returns (concat(Z1, Z2, Z3) [total, 96], Z4[:, 0] -- the SortPooling key, :82).
     With `batch` (the SubgraphBatch) and the reference's fp32 architecture (widths 32/32/32/1) layers 1..4 run as
     dense 32 x 32 block products on the matrix cores straight from the bit adjacency
-    (lpg_seal_conv_stack_f32; g / d_inv may then be None); otherwise the generic path:
+    (lpg_seal_conv_stack_f32; g / d_inv may then be None, and with h1 = first_layer_h1(...) so may x);
+    otherwise the generic path:
     4 x (linear + block-diagonal CSR SpMM with the fused tanh epilogue)."""
-    if batch is not None and _dense_ok(weights, x.dtype):
+    if batch is not None and _dense_ok(weights, torch.float32 if x is None else x.dtype):
         lib = _lib.load()
-        h1 = _ops.linear(x, weights[0], w_is_km=True)               # the one big matmul: X W_1
-        total = x.shape[0]
+        if h1 is None:
+            h1 = _ops.linear(x, weights[0], w_is_km=True)           # the one big matmul: X W_1
+        total = h1.shape[0]                                          # (h1 given: first_layer_h1, X never built)
         off = batch.node_off()
         n_win = -(-total // 128)
-        first = torch.searchsorted(off, torch.arange(n_win + 1, device=x.device, dtype=torch.int64) * 128)
+        first = torch.searchsorted(off, torch.arange(n_win + 1, device=h1.device, dtype=torch.int64) * 128)
         first = first.clamp_(max=batch.B).to(torch.int32)
-        cat = torch.empty((total, 96), dtype=torch.float32, device=x.device)
-        key = torch.empty(total, dtype=torch.float32, device=x.device)
+        cat = torch.empty((total, 96), dtype=torch.float32, device=h1.device)
+        key = torch.empty(total, dtype=torch.float32, device=h1.device)
         w2, w3, w4 = (_ops._c(w, torch.float32) for w in weights[1:])
         P = _ops._ptr
         _lib.check(lib.lpg_seal_conv_stack_f32(P(off), P(first), n_win, P(batch.adj_bits), P(h1), h1.stride(0), P(w2),
@@ -361,7 +393,10 @@ def score_links(positive, negative, nodes_size, emb, weights, head_weights, test
     """the SEAL scoring forward end to end for a candidate set: structure (a10-a12), graph
     convolutions (a9) and the head.  Returns (scores [B], labels [B,1], batch)."""
     batch, labels, T, tag_map, _ = link2subgraph(positive, negative, nodes_size, test_ratio, hop, device=device)
-    g, d_inv, x = gnn_inputs(batch, tag_map, T, emb, build_csr=not _dense_ok(weights))
-    z, key = graph_conv_stack(g, d_inv, x, weights, batch=batch)
+    if _dense_ok(weights) and emb is not None:          # X is never built: H_1 from two row gathers, then the dense stack
+        z, key = graph_conv_stack(None, None, None, weights, batch=batch, h1=first_layer_h1(batch, tag_map, T, emb, weights[0]))
+    else:
+        g, d_inv, x = gnn_inputs(batch, tag_map, T, emb)
+        z, key = graph_conv_stack(g, d_inv, x, weights, batch=batch)
     _, score = head(z, key, batch.node_off(), head_weights)
     return score, labels, batch

@@ -30,6 +30,10 @@ hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, device=dev) * 0.1, "conv1d_kerne
       "weight_2": torch.randn(128, 2, device=dev), "bias_2": torch.zeros(2, device=dev)}
 gw = [w.to(DT) for w in gw]
 t_conv, (z, key) = T(lambda: seal.graph_conv_stack(g, d_inv, x, gw, batch=None if GENERIC else batch))
+if not GENERIC:
+    t_h1, h1 = T(lambda: seal.first_layer_h1(batch, tag_map, Tn, emb, gw[0]))
+    t_conv2, _ = T(lambda: seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1))
+    print(f"table path: first_layer_h1 {t_h1:.3f} + dense stack {t_conv2:.3f} ms (replaces gnn_inputs + conv_stack)")
 z, key = z.float(), key.float()
 off = batch.node_off()
 t_head, _ = T(lambda: seal.head(z, key, off, hw))

@@ -621,6 +621,24 @@ def test_seal_auto_hop_matches_reference(dev, sl):
     assert T == 6
 
 
+def test_seal_first_layer_from_tables(dev, sl, golden_dir):
+    """H_1 = X W_1 computed as W_1[tag] + (emb W_1[T:])[node] without building X: against X @ W_1 in fp64 on the
+    exactly-checked X of gnn_inputs, with the shipped checkpoint's first-layer weights; bad node ids are flagged."""
+    from lpgnn_amd import seal
+    wz = np.load(os.path.join(golden_dir, "seal_weights.npz"))
+    w1 = torch.from_numpy(wz["graph_weight_1"]).to(dev)                 # [106, 32]
+    pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
+    emb = torch.from_numpy(np.random.default_rng(0).standard_normal((620, 100)).astype(np.float32)).to(dev)
+    batch, _, T, tag_map, _ = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev)
+    _, _, x = seal.gnn_inputs(batch, tag_map, T, emb, build_csr=False)
+    h1 = seal.first_layer_h1(batch, tag_map, T, emb, w1)
+    want = _np(x).astype(np.float64) @ wz["graph_weight_1"].astype(np.float64)
+    mag = np.abs(_np(x)).astype(np.float64) @ np.abs(wz["graph_weight_1"]).astype(np.float64)
+    assert h1.shape == (x.shape[0], 32) and np.all(np.abs(_np(h1) - want) <= TOL * mag + 1e-30)
+    with pytest.raises(IndexError):
+        seal.first_layer_h1(batch, tag_map, T, emb[:300], w1[: T + 100])      # node ids >= 300 exist in the batch
+
+
 def test_seal_dense_conv_stack_matches_generic_at_scale(dev):
     """the dense-block MFMA conv stack against the generic CSR path on a hub-rich synthetic batch (236 K-node RMAT
     graph, 20 K candidate pairs, subgraphs of 2..100 vertices incl. capped ones, max_neighbors = 128 as well):
@@ -657,8 +675,8 @@ def test_seal_head_with_reference_weights(dev, sl, golden_dir):
     pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
     emb = torch.from_numpy(np.random.default_rng(0).standard_normal((620, 100)).astype(np.float32)).to(dev)
     batch, labels, T, tag_map, _ = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev)
-    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb, build_csr=False)      # the path score_links takes
-    z, key = seal.graph_conv_stack(g, d_inv, x, gw, batch=batch)
+    h1 = seal.first_layer_h1(batch, tag_map, T, emb, gw[0])                      # the path score_links takes
+    z, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1)
     pre_y, score = seal.head(z, key, batch.node_off(), hw)
     assert pre_y.shape == (4202, 2) and score.shape == (4202,)
     off = _np(batch.node_off())
