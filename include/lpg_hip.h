@@ -169,6 +169,59 @@ int lpg_pair_readout_f32(const float* h, int64_t P, int64_t d, const int64_t* id
                          void* stream);
 int lpg_flip_index_i64(const int64_t* ei2, int64_t E2, int64_t* edge, int64_t* edge_r,
                        void* stream);
+/* ---------------------------------------------------------------- small-graph GCN blocks (a5-a8)
+ * The reference's own dataset (fb-pages-food: 620 nodes, 4252 tuples) is launch-bound: a
+ * GCNConv + GraphNorm + Dropout(eval) + ReLU block [TwoWL/model/model.py:36-41,73,77] runs as TWO
+ * launches here, for graphs of at most lpg_small_max_rows() rows with unit edge weights (PyG
+ * gcn_norm).  GraphNorm + ReLU are DEFERRED: the aggregation writes the un-normalised tensor y and
+ * per-row-block column sums `part` [row_blocks][2][C] (fp64: sum y, sum y^2); the consumer (next
+ * linear, readout) folds them in a fixed order and normalises while loading.  A deferred-norm
+ * descriptor is (part, gn_weight, gn_bias, gn_mean_scale, row_blocks, relu); part == NULL means
+ * "use the tensor as it is".
+ *
+ * lpg_embedding_graphnorm_f32: y = GraphNorm(table[idx])  [model.py:53-55,71], one launch.
+ * lpg_small_pack_build: packs a CSR graph's edge stream once per (graph, row_blocks):
+ *   (col | row << 16) words in [row block][strip step][thread] order; `plan` is the
+ *   lpg_csr_plan_build result for the same graph.
+ * lpg_small_linear_t_f32: hT[m, ldt] = (X W^T)^T (and h2T with W2), X by `mode`:
+ *   0: N_a(xa) [n,k];  1: N_a(xa[pos[t,0],:]) * N_a(xa[pos[t,1],:]), xa [n_src,k], pos [n,2]
+ *   [model.py:75];  2: N_a(xa) + N_b(xb) [model.py:77].  k <= 256; ldt % 4 == 0, >= n rounded up to 4.
+ * lpg_small_gcn_f32: y[n, ldo] (column c) = dinv * (A (dinv * h[:, c])) + bias[c] and `part`, for one
+ *   or two (graph, bias) sets in one launch (conv2s[i] / conv2s_r[i], model.py:77; both graphs packed
+ *   with the same e_cap and row_blocks); second set NULL = one side.  Atomic-free, fixed order.
+ * lpg_small_readout_f32: out[b] = sum_c x[idx[2b],c] * x[idx[2b+1],c] * w[c] + b0 with
+ *   x = N_a(ya) + N_r(yr)  (yr NULL: x = N_a(ya))  [model.py:77-83]. */
+int64_t lpg_small_max_rows(void);
+int64_t lpg_small_max_row_blocks(void);
+int lpg_embedding_graphnorm_f32(const float* table, int64_t n_table, int64_t d, const int64_t* idx,
+                                int64_t n, const float* weight, const float* bias,
+                                const float* mean_scale, float eps, int relu, float* y,
+                                int32_t* err_flag, void* stream);
+int64_t lpg_small_pack_bytes(int64_t e_cap, int64_t row_blocks);
+int lpg_small_pack_build(const void* plan, const int64_t* rowptr, const int32_t* col, int64_t n,
+                         int64_t e_cap, int64_t row_blocks, void* pack, int64_t pack_bytes,
+                         void* stream);
+int lpg_small_linear_t_f32(const float* xa, const float* xb, const int64_t* pos, int mode,
+                           int64_t n_src, int64_t n, int64_t k, const float* w, const float* w2,
+                           int64_t m, float* hT, float* h2T, int64_t ldt, const double* part_a,
+                           const float* gn_weight_a, const float* gn_bias_a,
+                           const float* gn_mean_scale_a, int64_t row_blocks_a, int relu_a,
+                           const double* part_b, const float* gn_weight_b, const float* gn_bias_b,
+                           const float* gn_mean_scale_b, int64_t row_blocks_b, int relu_b, float eps,
+                           int32_t* err_flag, void* stream);
+int lpg_small_gcn_f32(int64_t n, int64_t c, int64_t ldt, int64_t ldo, int64_t row_blocks,
+                      int64_t e_cap, const float* hT, const void* pack, const int64_t* rowptr,
+                      const float* dinv, const float* bias, float* y, double* part,
+                      const float* hT2, const void* pack2, const int64_t* rowptr2,
+                      const float* dinv2, const float* bias2, float* y2, double* part2,
+                      void* stream);
+int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C,
+                          const double* part_a, const float* gn_weight_a, const float* gn_bias_a,
+                          const float* gn_mean_scale_a, int64_t row_blocks_a, int relu_a,
+                          const double* part_r, const float* gn_weight_r, const float* gn_bias_r,
+                          const float* gn_mean_scale_r, int64_t row_blocks_r, int relu_r, float eps,
+                          const int64_t* idx, int64_t B, const float* w, const float* b0,
+                          float* out, int32_t* err_flag, void* stream);
 
 /* ---------------------------------------------------------------- 2-WL tuple graph (a3, a2)
  * get_ei2(n_node, pos_edge, pred_edge) [TwoWL/utils.py:36-45]: tuple ids = columns of

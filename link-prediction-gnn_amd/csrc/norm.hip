@@ -171,18 +171,38 @@ __global__ __launch_bounds__(kSmallBlock) void gn_small_kernel(const float* __re
                                                               const float* __restrict__ weight,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ mean_scale, float eps, int relu,
-                                                              const float* __restrict__ add_to, float* __restrict__ y) {
+                                                              const float* __restrict__ add_to, float* __restrict__ y,
+                                                              const int64_t* __restrict__ idx, int n_table,
+                                                              int32_t* err_flag) {
   __shared__ double red[2][kSmallBlock / 64][4];
   __shared__ float st[3][4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c = blockIdx.x * 4;
   float4 v[kSmallRows], a[kSmallRows];
+  // parameter loads up front (after the reductions they would be a round trip nothing hides)
+  const float p_w = (t < 4 && weight) ? weight[c + t] : 1.f, p_b = (t < 4 && bias) ? bias[c + t] : 0.f,
+              p_ms = (t < 4 && mean_scale) ? mean_scale[c + t] : 1.f;
+  int64_t src[kSmallRows];
 #pragma unroll
-  for (int k = 0; k < kSmallRows; ++k) {             // every load first (clamped rows), then the arithmetic
+  for (int k = 0; k < kSmallRows; ++k) {
     const int r = t + k * kSmallBlock;
-    const int64_t off = static_cast<int64_t>(r < n ? r : n - 1) * d + c;
-    v[k] = *reinterpret_cast<const float4*>(x + off);
+    src[k] = r < n ? r : n - 1;
   }
+  if (idx) {                                         // x is a table, row r of the input is x[idx[r]] (Embedding)
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) src[k] = idx[src[k]];     // every index load first
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) {
+      const bool b = src[k] < 0 || src[k] >= n_table;
+      bad |= b;
+      src[k] = b ? 0 : src[k];
+    }
+    if (bad) flag_error(err_flag, LPG_F_INDEX_RANGE);
+  }
+#pragma unroll
+  for (int k = 0; k < kSmallRows; ++k)               // every load first (clamped rows), then the arithmetic
+    v[k] = *reinterpret_cast<const float4*>(x + src[k] * d + c);
   asm volatile("" ::: "memory");
   double s[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -214,13 +234,13 @@ __global__ __launch_bounds__(kSmallBlock) void gn_small_kernel(const float* __re
     double ts = 0.0, ts2 = 0.0;
     for (int w = 0; w < kSmallBlock / 64; ++w) { ts += red[0][w][t]; ts2 += red[1][w][t]; }   // fixed order
     const double mean = ts / static_cast<double>(n), ex2 = ts2 / static_cast<double>(n);
-    const double ms = mean_scale ? static_cast<double>(mean_scale[c + t]) : 1.0;
+    const double ms = static_cast<double>(p_ms);
     double var = ex2 - mean * mean * ms * (2.0 - ms);
     if (var < 0.0) var = 0.0;
     const double inv = 1.0 / sqrt(var + static_cast<double>(eps));
     st[0][t] = static_cast<float>(mean * ms);
-    st[1][t] = static_cast<float>((weight ? static_cast<double>(weight[c + t]) : 1.0) * inv);
-    st[2][t] = bias ? bias[c + t] : 0.f;
+    st[1][t] = static_cast<float>(static_cast<double>(p_w) * inv);
+    st[2][t] = p_b;
   }
   __syncthreads();
   const float sh[4] = {st[0][0], st[0][1], st[0][2], st[0][3]}, sc[4] = {st[1][0], st[1][1], st[1][2], st[1][3]},
@@ -272,7 +292,8 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
     if (n <= kSmallRows * kSmallBlock && d % 4 == 0 && d / 4 < 65536 && al16(x) && al16(y) && (!add_to || al16(add_to)) &&
         !(env && atoi(env) == 0)) {
       hipLaunchKernelGGL(gn_small_kernel, dim3(static_cast<unsigned>(d / 4)), dim3(kSmallBlock), 0, st, x,
-                         static_cast<int>(n), static_cast<int>(d), weight, bias, mean_scale, eps, relu, add_to, y);
+                         static_cast<int>(n), static_cast<int>(d), weight, bias, mean_scale, eps, relu, add_to, y,
+                         static_cast<const int64_t*>(nullptr), 0, static_cast<int32_t*>(nullptr));
       return check_launch("graphnorm (one launch)");
     }
   }
@@ -297,4 +318,18 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
   else
     hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(grid_for(n * d)), dim3(kBlock), 0, st, x, n, d, stats, relu, add_to, y);
   return check_launch("graphnorm");
+}
+
+// GraphNorm(Embedding(idx)) in one launch for small n: the emb stage of LocalWLNet (TwoWL/model/model.py:53-55, :71).
+LPG_EXPORT int lpg_embedding_graphnorm_f32(const float* table, int64_t n_table, int64_t d, const int64_t* idx, int64_t n,
+                                           const float* weight, const float* bias, const float* mean_scale, float eps,
+                                           int relu, float* y, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(n >= 1 && n <= kSmallRows * kSmallBlock && d >= 4 && d % 4 == 0 && d / 4 < 65536 && n_table >= 1,
+              "embedding_graphnorm: needs 1 <= n <= %d rows and d %% 4 == 0", kSmallRows * kSmallBlock);
+  LPG_REQUIRE(table && idx && y && reinterpret_cast<uintptr_t>(table) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0,
+              "embedding_graphnorm: null or misaligned pointer");
+  hipLaunchKernelGGL(gn_small_kernel, dim3(static_cast<unsigned>(d / 4)), dim3(kSmallBlock), 0, as_stream(stream), table,
+                     static_cast<int>(n), static_cast<int>(d), weight, bias, mean_scale, eps, relu,
+                     static_cast<const float*>(nullptr), y, idx, static_cast<int>(n_table), err_flag);
+  return check_launch("embedding_graphnorm");
 }

@@ -1,0 +1,550 @@
+// Small-graph GCN blocks: the launch-bound regime of the reference's own dataset (fb-pages-food: N = 620 nodes,
+// P = 4252 tuples, 4 K / 74 K edges) where every kernel of the generic path lasts 2-5 us and the forward is
+// the number of launches.  A GCNConv + GraphNorm + Dropout(eval) + ReLU block (TwoWL/model/model.py:36-41,
+// :73, :77) becomes TWO launches instead of five or six:
+//
+//   sg_linear_t_kernel   hT[m][n] = (X W^T)^T, X given as rows, as the pair product x[pos[:,0]] * x[pos[:,1]]
+//                        (model.py:75, no [P,C] intermediate) or as the sum of the two orientation outputs of the
+//                        previous 2-WL layer (model.py:77); two weight matrices in one pass (conv2s / conv2s_r).
+//                        Output TRANSPOSED: a feature column is contiguous.
+//   sg_gcn_kernel        a 1024-thread workgroup owns (one feature column) x (one block of rows): the whole column
+//                        goes to LDS pre-scaled by D^-1/2, the block's rows are aggregated out of LDS, + bias,
+//                        stored row-major, and the block's column sums (y, y^2, fp64) are written as partials.
+//
+// GraphNorm + ReLU are DEFERRED to the consumer: its statistics are per column, the consumers (the next linear,
+// the readout) hold one column per lane, so a lane folds the few per-block partials (fixed order, fp64), derives
+// shift / scale once, and normalises values as it loads them.  No kernel ever waits for column statistics.
+//
+// Aggregation inside a workgroup: the block's edges (CSR order) are cut into 1024 strips, one per thread; a thread
+// walks its strip left to right and keeps the running sum of the current row.  Rows that begin and end inside a
+// strip are written straight to LDS; the first / last piece of a strip that may continue into a neighbour go
+// to per-thread slots, and after one barrier the thread that holds the FIRST piece of such a row adds the
+// following pieces in strip order.  No atomics, every sum has a fixed order => bitwise reproducible.  The edge
+// stream is pre-packed once per graph as (col | row << 16) words laid out [row block][strip step][thread] so
+// that the 16-byte loads of a wave are contiguous (lpg_small_pack_build); GCN weights are never read: w_e =
+// dinv[row] * dinv[col] (PyG gcn_norm with unit edge weights) is applied as a column pre-scale and a row scale.
+#include <stdlib.h>
+
+#include "lpg_common.hpp"
+
+namespace {
+using namespace lpg;
+
+constexpr int kSgBlock = 1024;        // threads of the column workgroup = strips of the edge stream
+constexpr int kSgMaxRows = 8192;      // rows a column workgroup can hold (2 x 32 KB of LDS)
+constexpr int kSgRowsPerThread = kSgMaxRows / kSgBlock;
+constexpr int kSgMaxRowBlocks = 8;
+constexpr uint32_t kSgPad = 0xFFFFFFFFu;
+
+__host__ __device__ inline int64_t sg_strip(int64_t E) {
+  const int64_t s = ((E > 0 ? E : 1) + kSgBlock - 1) / kSgBlock;      // >= 1 step even for an empty block
+  return (s + 3) & ~int64_t(3);
+}
+__host__ __device__ inline int sg_rows_per_block(int n, int rb) { return (n + rb - 1) / rb; }
+
+// block b: words [b * cap_words, ...); word (q * 1024 + t) * 4 + j  <->  edge e0 + t * S + 4 q + j
+__global__ __launch_bounds__(kBlock) void sg_pack_kernel(const int64_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col,
+                                                         const int32_t* __restrict__ rowid, int n, int rb,
+                                                         int64_t cap_words, uint32_t* __restrict__ pack) {
+  const int b = blockIdx.y;
+  const int rpb = sg_rows_per_block(n, rb);
+  const int r0 = b * rpb < n ? b * rpb : n, r1 = r0 + rpb < n ? r0 + rpb : n;
+  const int64_t e0 = rowptr[r0], e1 = rowptr[r1];
+  const int64_t S = sg_strip(e1 - e0);
+  const int64_t words = S * kSgBlock;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  uint32_t* __restrict__ out = pack + static_cast<int64_t>(b) * cap_words;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < words; i += stride) {
+    const int64_t q = i / (kSgBlock * 4), rem = i % (kSgBlock * 4);
+    const int64_t t = rem >> 2, j = rem & 3;
+    const int64_t e = e0 + t * S + 4 * q + j;
+    uint32_t w = kSgPad;
+    if (e < e1) w = (static_cast<uint32_t>(col[e]) & 0xFFFFu) | (static_cast<uint32_t>(rowid[e]) << 16);
+    out[i] = w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ deferred GraphNorm
+struct SgNorm {
+  const double* part;    // [rb][2][C] per-row-block sums of y and y^2, or null: the tensor is used as it is
+  const float* gw;       // GraphNorm weight / bias / mean_scale, [C] each or null
+  const float* gb;
+  const float* gms;
+  int rb, relu, n, C;    // n = rows the statistics cover
+  float eps;
+};
+
+struct SgCoef {
+  float sh, sc, bi;
+  int relu;
+};
+
+// torch_geometric.nn.GraphNorm (batch=None) [3P, TwoWL/model/model.py:38]: o = x - mean * mean_scale;
+// y = weight * o / sqrt(mean(o^2) + eps) + bias; one-pass variance in fp64 (var = E[x^2] - mean^2 ms (2 - ms)).
+__device__ __forceinline__ SgCoef sg_coef(const SgNorm& nm, int col) {
+  SgCoef c{0.f, 1.f, 0.f, 0};
+  if (!nm.part) return c;
+  double p0[kSgMaxRowBlocks], p1[kSgMaxRowBlocks];
+#pragma unroll
+  for (int b = 0; b < kSgMaxRowBlocks; ++b) {              // every load first, clamped
+    const int bb = b < nm.rb ? b : nm.rb - 1;
+    p0[b] = nm.part[(static_cast<int64_t>(bb) * 2 + 0) * nm.C + col];
+    p1[b] = nm.part[(static_cast<int64_t>(bb) * 2 + 1) * nm.C + col];
+  }
+  const float gw = nm.gw ? nm.gw[col] : 1.f, gb = nm.gb ? nm.gb[col] : 0.f, gms = nm.gms ? nm.gms[col] : 1.f;
+  double s = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int b = 0; b < kSgMaxRowBlocks; ++b)                // fixed order
+    if (b < nm.rb) { s += p0[b]; s2 += p1[b]; }
+  const double mean = s / static_cast<double>(nm.n), ex2 = s2 / static_cast<double>(nm.n);
+  const double ms = static_cast<double>(gms);
+  double var = ex2 - mean * mean * ms * (2.0 - ms);
+  if (var < 0.0) var = 0.0;
+  const double inv = 1.0 / sqrt(var + static_cast<double>(nm.eps));
+  c.sh = static_cast<float>(mean * ms);
+  c.sc = static_cast<float>(static_cast<double>(gw) * inv);
+  c.bi = gb;
+  c.relu = nm.relu;
+  return c;
+}
+__device__ __forceinline__ float sg_apply(const SgCoef& c, float y) {
+  const float o = (y - c.sh) * c.sc + c.bi;      // identity coefficients (0, 1, 0): exact
+  return (c.relu && o < 0.f) ? 0.f : o;
+}
+
+// ------------------------------------------------------------------------------------------------ linear
+// A wave owns 4 consecutive rows; lane l holds the contraction indices l, l + 64, ... (KPL of them), so a row
+// is one coalesced load per 64 values.  Outputs are produced 16 at a time: every lane forms its partial dot
+// products with the 16 weight rows, then a halving butterfly (8 + 4 + 2 + 1 + 2 shuffles instead of 16 x 6)
+// leaves output (lane >> 2) summed over all lanes; one lane in four stores the 4 rows as one 16-byte piece of the
+// transposed output.
+struct SgLinArgs {
+  const float* xa;       // mode 0: rows [n, k]; mode 1: table [n_src, k]; mode 2: first addend [n, k]
+  const float* xb;       // mode 2: second addend
+  const int64_t* pos;    // mode 1: [n, 2]
+  const float* w;        // [m, k]
+  const float* w2;       // [m, k] or null
+  float* hT;             // [m, ldt]
+  float* h2T;            // [m, ldt] or null
+  int32_t* err_flag;
+  int n, n_src, k, m, mode;
+  int64_t ldt;
+  SgNorm na, nb;         // deferred GraphNorm of xa / xb
+};
+
+// one halving step of the butterfly: lanes with bit OFF keep the upper HALF partials and hand over the lower ones
+template <int HALF, int OFF>
+__device__ __forceinline__ void sg_halve(float (&p)[16], int lane) {
+  const bool up = (lane & OFF) != 0;
+#pragma unroll
+  for (int q = 0; q < HALF; ++q) {
+    const float keep = up ? p[q + HALF] : p[q];
+    const float send = up ? p[q] : p[q + HALF];
+    p[q] = keep + __shfl_xor(send, OFF, 64);
+  }
+}
+
+template <int KPL>
+__device__ __forceinline__ void sg_load_w(const SgLinArgs& a, int pass, int tiles, int lane, float (&dst)[16][KPL]) {
+  const float* __restrict__ w = pass >= tiles ? a.w2 : a.w;
+  const int tile = pass >= tiles ? pass - tiles : pass;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    const int oo = tile * 16 + o < a.m ? tile * 16 + o : a.m - 1;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int kk = lane + 64 * j;
+      dst[o][j] = w[oo * a.k + (kk < a.k ? kk : a.k - 1)];
+    }
+  }
+}
+
+template <int KPL>
+__global__ __launch_bounds__(kBlock) void sg_linear_t_kernel(const SgLinArgs a) {
+  constexpr int TO = 16;                                   // outputs per pass: TO * KPL weight registers
+  const int lane = threadIdx.x & 63;
+  const int group = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int r0 = group * 4;
+  if (r0 >= a.n) return;                                   // wave-uniform
+  const int tiles = (a.m + TO - 1) / TO;
+  const int passes = a.w2 ? 2 * tiles : tiles;
+  // weights of pass 0 are requested before anything else; pass p + 1 is requested before pass p is consumed
+  float wf[TO][KPL], wn[TO][KPL];
+  sg_load_w<KPL>(a, 0, tiles, lane, wf);
+  float x[4][KPL];
+  {
+    int64_t ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = rb[i] = r0 + i < a.n ? r0 + i : a.n - 1;   // clamped rows: finite duplicates, stored into padding
+    if (a.mode == 1) {
+      int64_t p0[4], p1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                        // all eight index loads first
+        p0[i] = a.pos[2 * ra[i]];
+        p1[i] = a.pos[2 * ra[i] + 1];
+      }
+      bool bad = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool b = p0[i] < 0 || p0[i] >= a.n_src || p1[i] < 0 || p1[i] >= a.n_src;
+        bad |= b;
+        ra[i] = b ? 0 : p0[i];
+        rb[i] = b ? 0 : p1[i];
+      }
+      if (bad && lane == 0) flag_error(a.err_flag, LPG_F_INDEX_RANGE);
+    }
+    float u[4][KPL], v[4][KPL];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) {
+        const int kk = lane + 64 * j;
+        const int kc = kk < a.k ? kk : a.k - 1;            // unconditional clamped loads, selects afterwards
+        u[i][j] = a.xa[ra[i] * a.k + kc];
+        v[i][j] = a.mode == 0 ? 0.f : (a.mode == 1 ? a.xa[rb[i] * a.k + kc] : a.xb[rb[i] * a.k + kc]);
+      }
+    SgCoef ca[KPL], cb[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int kk = lane + 64 * j;
+      const int kc = kk < a.k ? kk : a.k - 1;
+      ca[j] = sg_coef(a.na, kc);
+      cb[j] = a.mode == 2 ? sg_coef(a.nb, kc) : ca[j];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) {
+        const float fu = sg_apply(ca[j], u[i][j]), fv = sg_apply(cb[j], v[i][j]);
+        const float t = a.mode == 0 ? fu : (a.mode == 1 ? fu * fv : fu + fv);
+        x[i][j] = lane + 64 * j < a.k ? t : 0.f;
+      }
+  }
+  for (int pass = 0; pass < passes; ++pass) {
+    if (pass + 1 < passes) sg_load_w<KPL>(a, pass + 1, tiles, lane, wn);
+    float* __restrict__ out = pass >= tiles ? a.h2T : a.hT;
+    const int tile = pass >= tiles ? pass - tiles : pass;
+    float res[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float p[TO];
+#pragma unroll
+      for (int o = 0; o < TO; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) s = fmaf(x[i][j], wf[o][j], s);     // x is 0 beyond k: clamped w is harmless
+        p[o] = s;
+      }
+      sg_halve<8, 32>(p, lane);                        // compile-time steps: p stays in registers
+      sg_halve<4, 16>(p, lane);
+      sg_halve<2, 8>(p, lane);
+      sg_halve<1, 4>(p, lane);
+      p[0] += __shfl_xor(p[0], 2, 64);
+      res[i] = p[0] + __shfl_xor(p[0], 1, 64);
+      __builtin_amdgcn_sched_barrier(0);               // one row's partials at a time (else the rows interleave and spill)
+    }
+    const int o = tile * TO + (lane >> 2);
+    if ((lane & 3) == 0 && o < a.m)
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(o) * a.ldt + r0) = make_float4(res[0], res[1], res[2], res[3]);
+    if (pass + 1 < passes) {
+#pragma unroll
+      for (int o2 = 0; o2 < TO; ++o2)
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) wf[o2][j] = wn[o2][j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ aggregation
+struct SgSide {
+  const float* hT;          // [c, ldt] transposed features (sg_linear_t_kernel)
+  const uint32_t* pack;     // packed edge stream of this side's graph (rb row blocks)
+  const int64_t* rowptr;    // [n + 1]
+  const float* dinv;        // [n] D^-1/2
+  const float* bias;        // [c] or null (GCNConv.bias)
+  float* y;                 // [n, ldo] row-major: A_hat h + bias, NOT yet normalised
+  double* part;             // [rb][2][c] column sums of y and y^2 per row block
+};
+
+__global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const SgSide s1, int n, int rb, int64_t ldt,
+                                                          int64_t ldo, int64_t cap_words) {
+  __shared__ float hs[kSgMaxRows];
+  __shared__ float acc[kSgMaxRows];
+  __shared__ int first_row[kSgBlock], last_row[kSgBlock];
+  __shared__ float l_sum[kSgBlock];
+  __shared__ double red[2][kSgBlock / 64];
+  const SgSide s = blockIdx.z ? s1 : s0;
+  const int c = blockIdx.x, blk = blockIdx.y, C = gridDim.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int rpb = sg_rows_per_block(n, rb);
+  const int r0 = blk * rpb < n ? blk * rpb : n, r1 = r0 + rpb < n ? r0 + rpb : n;
+  // every parameter / index load up front
+  const int64_t e0 = s.rowptr[r0], e1 = s.rowptr[r1];
+  const float bias = s.bias ? s.bias[c] : 0.f;
+  const uint4* __restrict__ pk = reinterpret_cast<const uint4*>(s.pack + static_cast<int64_t>(blk) * cap_words);
+  float dv[kSgRowsPerThread];
+  {
+    float hv[kSgRowsPerThread], dd[kSgRowsPerThread];
+#pragma unroll
+    for (int i = 0; i < kSgRowsPerThread; ++i) {
+      const int r = t + i * kSgBlock;
+      const int rc = r < n ? r : n - 1;
+      hv[i] = s.hT[static_cast<int64_t>(c) * ldt + rc];
+      dd[i] = s.dinv[rc];
+      const int rl = r0 + r;
+      dv[i] = s.dinv[rl < n ? rl : n - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < kSgRowsPerThread; ++i) {
+      const int r = t + i * kSgBlock;
+      if (r < n) hs[r] = hv[i] * dd[i];
+      if (r < r1 - r0) acc[r] = 0.f;
+    }
+  }
+  const int Q = static_cast<int>(sg_strip(e1 - e0) >> 2);   // 16-byte steps of a strip
+  constexpr int kBatch = 6;
+  uint4 u[kBatch], un[kBatch];
+#pragma unroll
+  for (int b = 0; b < kBatch; ++b) u[b] = pk[static_cast<int64_t>(b < Q ? b : Q - 1) * kSgBlock + t];
+  __syncthreads();
+
+  // ---- strip walk: the loads of step group b + 1 are in flight while group b is walked
+  int first = -1, cur = -1;
+  float sum = 0.f, lpiece = 0.f;
+  for (int q0 = 0; q0 < Q; q0 += kBatch) {
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const int q = q0 + kBatch + b < Q ? q0 + kBatch + b : Q - 1;
+      un[b] = pk[static_cast<int64_t>(q) * kSgBlock + t];
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const bool live = q0 + b < Q;
+      const uint32_t w4[4] = {u[b].x, u[b].y, u[b].z, u[b].w};
+      float v4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v4[j] = hs[(live && w4[j] != kSgPad) ? (w4[j] & 0xFFFFu) : 0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (live && w4[j] != kSgPad) {
+          const int r = static_cast<int>(w4[j] >> 16) - r0;
+          if (r != cur) {
+            if (cur >= 0) {
+              if (cur == first) lpiece = sum;          // the strip's first row ends here
+              else acc[cur] = sum;                     // a row that begins and ends inside this strip
+            } else {
+              first = r;
+            }
+            cur = r;
+            sum = 0.f;
+          }
+          sum += v4[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) u[b] = un[b];
+  }
+  const bool single = cur == first;                    // one row (or nothing) in the whole strip
+  if (cur >= 0 && single) lpiece = sum;
+  first_row[t] = first;
+  last_row[t] = cur;
+  l_sum[t] = lpiece;
+  __syncthreads();
+
+  // ---- rows cut by strip borders: the holder of a row's FIRST piece adds the following pieces in strip order
+  if (first >= 0) {
+    const int prev_last = t > 0 ? last_row[t - 1] : -1;
+    if (prev_last != first) {
+      float total = lpiece;
+      if (single)
+        for (int tt = t + 1; tt < kSgBlock && first_row[tt] == first; ++tt) {
+          total += l_sum[tt];
+          if (last_row[tt] != first) break;
+        }
+      acc[first] = total;
+    }
+    if (!single) {
+      float total = sum;
+      for (int tt = t + 1; tt < kSgBlock && first_row[tt] == cur; ++tt) {
+        total += l_sum[tt];
+        if (last_row[tt] != cur) break;
+      }
+      acc[cur] = total;
+    }
+  }
+  __syncthreads();
+
+  // ---- dinv[row] * sum + bias -> y; the block's column sums for the deferred GraphNorm
+  double ds = 0.0, ds2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < kSgRowsPerThread; ++i) {
+    const int r = t + i * kSgBlock;
+    if (r < r1 - r0) {
+      const float y = fmaf(acc[r], dv[i], bias);
+      s.y[static_cast<int64_t>(r0 + r) * ldo + c] = y;
+      const double q = static_cast<double>(y);
+      ds += q;
+      ds2 += q * q;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ds += __shfl_xor(ds, o);
+    ds2 += __shfl_xor(ds2, o);
+  }
+  if (lane == 0) { red[0][wave] = ds; red[1][wave] = ds2; }
+  __syncthreads();
+  if (t < 2) {
+    double ts = 0.0;
+    for (int w = 0; w < kSgBlock / 64; ++w) ts += red[t][w];                           // fixed order
+    s.part[(static_cast<int64_t>(blk) * 2 + t) * C + c] = ts;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ readout
+// TwoWL/model/model.py:78-83 over the two orientation outputs of the last 2-WL layer, both still un-normalised:
+// x = relu(GN_a(ya)) + relu(GN_r(yr)); out[b] = sum_c x[idx[2b], c] * x[idx[2b+1], c] * w[c] + b0.
+// One wave per scored edge, lanes = channels (each lane derives its channel's shift / scale once).
+__global__ __launch_bounds__(kBlock) void sg_readout_kernel(const float* __restrict__ ya, const float* __restrict__ yr,
+                                                            int P, int C, const SgNorm na, const SgNorm nr,
+                                                            const int64_t* __restrict__ idx, int B,
+                                                            const float* __restrict__ w, const float* __restrict__ b0,
+                                                            float* __restrict__ out, int32_t* err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * kBlock) >> 6;
+  const float bb = b0 ? b0[0] : 0.f;
+  for (int cb = 0; cb < C; cb += 64) {                      // C <= 64 in every reference configuration: one pass
+    const int c = cb + lane < C ? cb + lane : C - 1;
+    const SgCoef ca = sg_coef(na, c), cr = yr ? sg_coef(nr, c) : ca;
+    const float wc = cb + lane < C ? w[c] : 0.f;
+    for (int b = wave; b < B; b += nwaves) {
+      const int64_t i0 = idx[2 * b], i1 = idx[2 * b + 1];
+      if (i0 < 0 || i0 >= P || i1 < 0 || i1 >= P) {
+        if (lane == 0 && cb == 0) flag_error(err_flag, LPG_F_INDEX_RANGE);
+        continue;
+      }
+      const float a0 = ya[i0 * C + c], a1 = ya[i1 * C + c];
+      float q0 = 0.f, q1 = 0.f;
+      if (yr) { q0 = yr[i0 * C + c]; q1 = yr[i1 * C + c]; }
+      float x0 = sg_apply(ca, a0), x1 = sg_apply(ca, a1);
+      if (yr) { x0 += sg_apply(cr, q0); x1 += sg_apply(cr, q1); }
+      float sacc = x0 * x1 * wc;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+      if (lane == 0) out[b] = cb == 0 ? sacc + bb : out[b] + sacc;
+    }
+  }
+}
+
+inline bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+inline bool rb_ok(int64_t rb) { return rb >= 1 && rb <= kSgMaxRowBlocks; }
+
+bool make_norm(SgNorm* nm, const double* part, const float* gw, const float* gb, const float* gms, int64_t rb, int relu,
+               int64_t n_stat, int64_t C, float eps) {
+  nm->part = part; nm->gw = gw; nm->gb = gb; nm->gms = gms;
+  nm->rb = static_cast<int>(rb); nm->relu = relu; nm->n = static_cast<int>(n_stat); nm->C = static_cast<int>(C);
+  nm->eps = eps;
+  return !part || (rb_ok(rb) && n_stat >= 1);
+}
+}  // namespace
+
+LPG_EXPORT int64_t lpg_small_max_rows(void) { return kSgMaxRows; }
+LPG_EXPORT int64_t lpg_small_max_row_blocks(void) { return kSgMaxRowBlocks; }
+
+LPG_EXPORT int64_t lpg_small_pack_bytes(int64_t e_cap, int64_t row_blocks) {
+  if (e_cap < 0 || !rb_ok(row_blocks)) return LPG_E_INVALID;
+  return row_blocks * sg_strip(e_cap) * kSgBlock * 4;
+}
+
+LPG_EXPORT int lpg_small_pack_build(const void* plan, const int64_t* rowptr, const int32_t* col, int64_t n,
+                                    int64_t e_cap, int64_t row_blocks, void* pack, int64_t pack_bytes, void* stream) {
+  LPG_REQUIRE(n >= 1 && n <= kSgMaxRows && e_cap >= 0 && rb_ok(row_blocks),
+              "small_pack_build: needs 1 <= n <= %d rows, 1 <= row_blocks <= %d", kSgMaxRows, kSgMaxRowBlocks);
+  LPG_REQUIRE(plan && rowptr && pack && (e_cap == 0 || col), "small_pack_build: null pointer");
+  LPG_REQUIRE(al16(pack), "small_pack_build: pack must be 16-byte aligned");
+  if (pack_bytes < lpg_small_pack_bytes(e_cap, row_blocks)) {
+    set_error("small_pack_build: buffer too small");
+    return LPG_E_WORKSPACE;
+  }
+  const int32_t* rowid = reinterpret_cast<const int32_t*>(static_cast<const char*>(plan) + 256);
+  const int64_t cap_words = sg_strip(e_cap) * kSgBlock;
+  hipLaunchKernelGGL(sg_pack_kernel, dim3(grid_for(cap_words, kBlock, 256), static_cast<unsigned>(row_blocks)), dim3(kBlock),
+                     0, as_stream(stream), rowptr, col, rowid, static_cast<int>(n), static_cast<int>(row_blocks), cap_words,
+                     static_cast<uint32_t*>(pack));
+  return check_launch("small_pack_build");
+}
+
+LPG_EXPORT int lpg_small_linear_t_f32(const float* xa, const float* xb, const int64_t* pos, int mode, int64_t n_src,
+                                      int64_t n, int64_t k, const float* w, const float* w2, int64_t m, float* hT,
+                                      float* h2T, int64_t ldt, const double* part_a, const float* gn_weight_a,
+                                      const float* gn_bias_a, const float* gn_mean_scale_a, int64_t row_blocks_a,
+                                      int relu_a, const double* part_b, const float* gn_weight_b, const float* gn_bias_b,
+                                      const float* gn_mean_scale_b, int64_t row_blocks_b, int relu_b, float eps,
+                                      int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(n >= 0 && k >= 1 && k <= 256 && m >= 1 && mode >= 0 && mode <= 2, "small_linear_t: bad sizes (k <= 256)");
+  if (n == 0) return LPG_OK;
+  LPG_REQUIRE(n <= (int64_t(1) << 30) && xa && w && hT && (!w2 || h2T), "small_linear_t: null pointer");
+  LPG_REQUIRE((mode != 1 || (pos && n_src >= 1)) && (mode != 2 || xb), "small_linear_t: mode operand missing");
+  LPG_REQUIRE(ldt >= n && ldt % 4 == 0 && ldt >= ((n + 3) & ~int64_t(3)) && al16(hT) && (!h2T || al16(h2T)),
+              "small_linear_t: ldt must be a multiple of 4 covering n rounded up to 4, outputs 16-byte aligned");
+  SgLinArgs a;
+  a.xa = xa; a.xb = xb; a.pos = pos; a.w = w; a.w2 = w2; a.hT = hT; a.h2T = h2T; a.err_flag = err_flag;
+  a.n = static_cast<int>(n); a.n_src = static_cast<int>(mode == 1 ? n_src : n); a.k = static_cast<int>(k);
+  a.m = static_cast<int>(m); a.mode = mode; a.ldt = ldt;
+  const int64_t n_stat = mode == 1 ? n_src : n;
+  LPG_REQUIRE(make_norm(&a.na, part_a, gn_weight_a, gn_bias_a, gn_mean_scale_a, row_blocks_a, relu_a, n_stat, k, eps) &&
+              make_norm(&a.nb, part_b, gn_weight_b, gn_bias_b, gn_mean_scale_b, row_blocks_b, relu_b, n_stat, k, eps),
+              "small_linear_t: bad deferred-norm descriptor");
+  const int64_t groups = ceil_div(n, 4);
+  const dim3 grid(static_cast<unsigned>(ceil_div(groups, kBlock / kWave))), blk(kBlock);
+  hipStream_t st = as_stream(stream);
+  switch ((k + 63) / 64) {
+    case 1: hipLaunchKernelGGL(sg_linear_t_kernel<1>, grid, blk, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(sg_linear_t_kernel<2>, grid, blk, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(sg_linear_t_kernel<3>, grid, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL(sg_linear_t_kernel<4>, grid, blk, 0, st, a); break;
+  }
+  return check_launch("small_linear_t");
+}
+
+LPG_EXPORT int lpg_small_gcn_f32(int64_t n, int64_t c, int64_t ldt, int64_t ldo, int64_t row_blocks, int64_t e_cap,
+                                 const float* hT, const void* pack, const int64_t* rowptr, const float* dinv,
+                                 const float* bias, float* y, double* part, const float* hT2, const void* pack2,
+                                 const int64_t* rowptr2, const float* dinv2, const float* bias2, float* y2,
+                                 double* part2, void* stream) {
+  LPG_REQUIRE(n >= 1 && n <= kSgMaxRows && c >= 1 && c < 65536 && rb_ok(row_blocks) && e_cap >= 0,
+              "small_gcn: needs 1 <= n <= %d, 1 <= row_blocks <= %d", kSgMaxRows, kSgMaxRowBlocks);
+  LPG_REQUIRE(hT && pack && rowptr && dinv && y && part && ldt >= n && ldo >= c, "small_gcn: bad argument");
+  const bool two = hT2 != nullptr;
+  LPG_REQUIRE(!two || (pack2 && rowptr2 && dinv2 && y2 && part2), "small_gcn: second side incomplete");
+  LPG_REQUIRE(al16(pack) && (!two || al16(pack2)), "small_gcn: pack must be 16-byte aligned");
+  SgSide s0{hT, static_cast<const uint32_t*>(pack), rowptr, dinv, bias, y, part};
+  SgSide s1 = s0;
+  if (two) s1 = SgSide{hT2, static_cast<const uint32_t*>(pack2), rowptr2, dinv2, bias2, y2, part2};
+  hipLaunchKernelGGL(sg_gcn_kernel, dim3(static_cast<unsigned>(c), static_cast<unsigned>(row_blocks), two ? 2 : 1),
+                     dim3(kSgBlock), 0, as_stream(stream), s0, s1, static_cast<int>(n), static_cast<int>(row_blocks), ldt,
+                     ldo, sg_strip(e_cap) * kSgBlock);
+  return check_launch("small_gcn");
+}
+
+LPG_EXPORT int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C, const double* part_a,
+                                     const float* gn_weight_a, const float* gn_bias_a, const float* gn_mean_scale_a,
+                                     int64_t row_blocks_a, int relu_a, const double* part_r, const float* gn_weight_r,
+                                     const float* gn_bias_r, const float* gn_mean_scale_r, int64_t row_blocks_r,
+                                     int relu_r, float eps, const int64_t* idx, int64_t B, const float* w,
+                                     const float* b0, float* out, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(P >= 0 && C >= 1 && B >= 0 && P < (int64_t(1) << 31) && B < (int64_t(1) << 31), "small_readout: bad sizes");
+  if (B == 0) return LPG_OK;
+  LPG_REQUIRE(ya && idx && w && out && P >= 1, "small_readout: null pointer");
+  SgNorm na, nr;
+  LPG_REQUIRE(make_norm(&na, part_a, gn_weight_a, gn_bias_a, gn_mean_scale_a, row_blocks_a, relu_a, P, C, eps) &&
+              make_norm(&nr, part_r, gn_weight_r, gn_bias_r, gn_mean_scale_r, row_blocks_r, relu_r, P, C, eps),
+              "small_readout: bad deferred-norm descriptor");
+  hipLaunchKernelGGL(sg_readout_kernel, dim3(grid_for(B * 64)), dim3(kBlock), 0, as_stream(stream), ya, yr,
+                     static_cast<int>(P), static_cast<int>(C), na, nr, idx, static_cast<int>(B), w, b0, out, err_flag);
+  return check_launch("small_readout");
+}

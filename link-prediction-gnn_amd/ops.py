@@ -118,6 +118,7 @@ class CSRGraph:
         self.device = rowptr.device
         self._plan = None
         self._ws = {}
+        self.unit_gcn = False      # gcn-normalised from unit edge weights: val[e] == dinv[row] * dinv[col]
         self.n_empty = -1          # rows without edges, once known on the host (0 skips a launch)
         self.max_row = -1          # longest row, once known on the host (short rows: one-launch row-parallel SpMM)
 
@@ -186,10 +187,23 @@ class CSRGraph:
         self.dinv = torch.empty(max(self.n_rows, 1), dtype=torch.float32, device=self.device)
         _lib.check(lib.lpg_gcn_norm_csr(_ptr(self._plan), _ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
                                         _ptr(self.dinv), self.n_rows, self.e_cap, int(unit), _stream()), "gcn_norm_csr")
+        self.unit_gcn = unit
         return self
 
     def nnz(self):
         return int(self.rowptr[-1].item())
+
+    def small_pack(self, row_blocks=1):
+        """packed (col | row << 16) edge stream of the small-graph kernels, built once per (graph, row_blocks)."""
+        pk = self._ws.get(("small_pack", row_blocks))
+        if pk is None:
+            lib = _lib.load()
+            nbytes = _lib.check(lib.lpg_small_pack_bytes(self.e_cap, row_blocks), "small_pack_bytes")
+            pk = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(lib.lpg_small_pack_build(_ptr(self._plan), _ptr(self.rowptr), _ptr(self.col), self.n_rows,
+                                                self.e_cap, row_blocks, _ptr(pk), nbytes, _stream()), "small_pack_build")
+            self._ws[("small_pack", row_blocks)] = pk
+        return pk
 
     # -- the hot op --------------------------------------------------------------------------
     def _workspace(self, d):
@@ -318,6 +332,143 @@ def pair_readout(h, idx, w, b):
     _lib.check(lib.lpg_pair_readout_f32(_ptr(h), h.shape[0], h.shape[1], _ptr(idx), B,
                                         _ptr(_c(w.reshape(-1), torch.float32)), _ptr(_c(b, torch.float32)),
                                         _ptr(out), _ptr(err_flag(h.device)), _stream()), "pair_readout")
+    return out
+
+
+# ------------------------------------------------------------------------------ small-graph GCN blocks
+_small_limits = None
+
+
+def small_max_rows():
+    global _small_limits
+    if _small_limits is None:
+        lib = _lib.load()
+        _small_limits = (int(lib.lpg_small_max_rows()), int(lib.lpg_small_max_row_blocks()))
+    return _small_limits[0]
+
+
+def small_row_blocks(e_cap):
+    """row blocks a graph's aggregation is cut into (more workgroups, shorter edge strips per thread)."""
+    small_max_rows()
+    env = os.environ.get("LPG_SG_ROW_BLOCKS")
+    rb = int(env) if env else (1 if e_cap < 16384 else 2 if e_cap < 32768 else 4 if e_cap < 131072 else 8)
+    return max(1, min(rb, _small_limits[1]))
+
+
+class Deferred:
+    """an un-normalised aggregation output y [n, C] plus what its consumers need to apply GraphNorm (+ ReLU) on
+    load: per-row-block column sums `part` [rb, 2, C] (fp64) and the norm's parameters."""
+
+    def __init__(self, y, part=None, norm=None, relu=False):
+        self.y, self.part, self.norm, self.relu = y, part, norm, relu
+
+    def args(self):
+        if self.part is None:
+            return [0, 0, 0, 0, 1, 0]
+        nm = self.norm
+        return [_ptr(self.part), _ptr(_c(nm.weight, torch.float32)), _ptr(_c(nm.bias, torch.float32)),
+                _ptr(_c(nm.mean_scale, torch.float32)), self.part.shape[0], int(self.relu)]
+
+    @property
+    def eps(self):
+        return float(self.norm.eps) if self.norm is not None else 1e-5
+
+    def materialize(self):
+        """the normalised tensor (tests / debugging): plain GraphNorm math on the device in fp64."""
+        if self.part is None:
+            return self.y
+        nm, n = self.norm, self.y.shape[0]
+        s, s2 = self.part[:, 0, :].sum(0), self.part[:, 1, :].sum(0)
+        mean, ms = s / n, nm.mean_scale.double()
+        var = (s2 / n - mean * mean * ms * (2.0 - ms)).clamp_min(0.0)
+        o = (self.y.double() - mean * ms) * (nm.weight.double() / torch.sqrt(var + nm.eps)) + nm.bias.double()
+        return (o.clamp_min(0.0) if self.relu else o).float()
+
+
+def embedding_graph_norm(table, idx, weight, bias, mean_scale, eps=1e-5, relu=False):
+    """GraphNorm(table[idx]) in one launch (n <= 8192 rows, d % 4 == 0)."""
+    lib = _lib.load()
+    _need_gpu(table, idx, weight, bias, mean_scale)
+    table = _c(table, torch.float32)
+    idx = _c(idx.reshape(-1), torch.int64)
+    n, d = idx.numel(), table.shape[1]
+    out = torch.empty((n, d), dtype=torch.float32, device=table.device)
+    _lib.check(lib.lpg_embedding_graphnorm_f32(_ptr(table), table.shape[0], d, _ptr(idx), n,
+                                               _ptr(_c(weight, torch.float32)), _ptr(_c(bias, torch.float32)),
+                                               _ptr(_c(mean_scale, torch.float32)), float(eps), int(relu), _ptr(out),
+                                               _ptr(err_flag(table.device)), _stream()), "embedding_graphnorm")
+    return out
+
+
+def small_linear_t(xa, weight, weight2=None, xb=None, pos=None):
+    """(X W^T)^T as [m, ldt] (columns contiguous, ldt = n rounded up to 4); X = N(xa), N(xa)[pos[:,0]] * N(xa)[pos[:,1]]
+    (pos given) or N(xa) + N(xb) (xb given), N = the deferred GraphNorm when the operand is a `Deferred`.
+    weight2: a second [m,k] matrix over the same X (second return value)."""
+    lib = _lib.load()
+    xa = xa if isinstance(xa, Deferred) else Deferred(xa)
+    xb = xb if (xb is None or isinstance(xb, Deferred)) else Deferred(xb)
+    ya, yb = _c(xa.y, torch.float32), (None if xb is None else _c(xb.y, torch.float32))
+    _need_gpu(ya, yb, pos, weight, weight2)
+    weight, weight2 = _c(weight, torch.float32), _c(weight2, torch.float32)
+    m, k = weight.shape
+    if ya.dim() != 2 or ya.shape[1] != k or (weight2 is not None and weight2.shape != weight.shape):
+        raise ValueError("small_linear_t: shape mismatch")
+    mode, n, n_src = 0, ya.shape[0], ya.shape[0]
+    if pos is not None:
+        pos = _c(pos, torch.int64)
+        mode, n = 1, pos.shape[0]
+    elif yb is not None:
+        if yb.shape != ya.shape:
+            raise ValueError("small_linear_t: xa / xb shape mismatch")
+        mode = 2
+    ldt = (n + 3) // 4 * 4
+    hT = torch.empty((m, ldt), dtype=torch.float32, device=ya.device)
+    h2T = torch.empty((m, ldt), dtype=torch.float32, device=ya.device) if weight2 is not None else None
+    nb = xb.args() if xb is not None else Deferred(None).args()
+    _lib.check(lib.lpg_small_linear_t_f32(_ptr(ya), _ptr(yb), _ptr(pos), mode, n_src, n, k, _ptr(weight), _ptr(weight2),
+                                          m, _ptr(hT), _ptr(h2T), ldt, *xa.args(), *nb, xa.eps,
+                                          _ptr(err_flag(ya.device)), _stream()), "small_linear_t")
+    return (hT, h2T) if weight2 is not None else hT
+
+
+def small_gcn(n, sides):
+    """sides: one or two tuples (hT [c, ldt], graph: gcn-normalised unit-weight CSRGraph of n rows, conv bias, norm
+    module, relu); one launch; returns a `Deferred` (un-normalised A_hat h + bias, column-sum partials) per side."""
+    lib = _lib.load()
+    c, ldt = sides[0][0].shape
+    e_cap = sides[0][1].e_cap
+    rb = small_row_blocks(e_cap)
+    outs, args = [], []
+    for hT, g, b, norm, relu in sides:
+        _need_gpu(hT, b)
+        if (hT.shape != (c, ldt) or not hT.is_contiguous() or g.n_rows != n or g.n_cols != n or not g.unit_gcn
+                or g.e_cap != e_cap):
+            raise ValueError("small_gcn: side does not match (square unit-weight gcn-normalised graph of n rows)")
+        y = torch.empty((n, c), dtype=torch.float32, device=hT.device)
+        part = torch.empty((rb, 2, c), dtype=torch.float64, device=hT.device)
+        outs.append(Deferred(y, part, norm, relu))
+        args += [_ptr(hT), _ptr(g.small_pack(rb)), _ptr(g.rowptr), _ptr(g.dinv), _ptr(_c(b, torch.float32)), _ptr(y),
+                 _ptr(part)]
+    if len(sides) == 1:
+        args += [0] * 7
+    _lib.check(lib.lpg_small_gcn_f32(n, c, ldt, c, rb, e_cap, *args, _stream()), "small_gcn")
+    return outs
+
+
+def small_readout(a, r, idx, w, b):
+    """pair readout over N(a) + N(r) (r may be None); a, r: `Deferred` [P, C]."""
+    lib = _lib.load()
+    ya, yr = _c(a.y, torch.float32), (None if r is None else _c(r.y, torch.float32))
+    _need_gpu(ya, yr, idx, w, b)
+    if yr is not None and yr.shape != ya.shape:
+        raise ValueError("small_readout: shape mismatch")
+    idx = _c(idx.reshape(-1), torch.int64)
+    B = idx.numel() // 2
+    out = torch.empty((B, 1), dtype=torch.float32, device=ya.device)
+    nr = r.args() if r is not None else Deferred(None).args()
+    _lib.check(lib.lpg_small_readout_f32(_ptr(ya), _ptr(yr), ya.shape[0], ya.shape[1], *a.args(), *nr, a.eps, _ptr(idx),
+                                         B, _ptr(_c(w.reshape(-1), torch.float32)), _ptr(_c(b, torch.float32)),
+                                         _ptr(out), _ptr(err_flag(ya.device)), _stream()), "small_readout")
     return out
 
 

@@ -42,6 +42,17 @@ def double(x, for_index=False):
 
 _side_streams = {}
 _PARALLEL_BRANCHES = os.environ.get("LPG_TWOWL_PARALLEL", "1") != "0"
+_SMALL_PATH = os.environ.get("LPG_TWOWL_SMALL", "1") != "0"      # A/B hook: 0 keeps the kernel-per-op path
+
+
+def _is_relu_conv(seq):
+    m = list(seq.modlist)
+    return (len(m) == 4 and isinstance(m[0], GCNConv) and isinstance(m[1], GraphNorm) and isinstance(m[2], nn.Dropout)
+            and isinstance(m[3], (nn.ReLU, nn.Identity)))
+
+
+def _side(hT, g, seq):
+    return (hT, g, seq.modlist[0].bias, seq.modlist[1], isinstance(seq.modlist[3], nn.ReLU))
 
 
 class Seq(nn.Module):
@@ -95,6 +106,8 @@ class LocalWLNet(nn.Module):
         P = pos.shape[0]
         edge2 = graph_cache.get(ei2, None, P, True, flip=1)
         edge2_r = graph_cache.get(ei2, None, P, True, flip=2)
+        if self._small_graph_ok(x, edge1, P):
+            return self._forward_small(x, edge1, pos, idx, edge2, edge2_r)
         x = _ops.embedding(self.emb[0].weight, x)                      # Embedding(deg)
         x = self.emb[1](x)                                             # GraphNorm (Dropout: eval identity)
         for conv1 in self.conv1s:
@@ -103,6 +116,42 @@ class LocalWLNet(nn.Module):
         for i in range(len(self.conv2s)):
             x = self._both_orientations(self.conv2s[i], self.conv2s_r[i], x, edge2, edge2_r)   # a7
         out = _ops.pair_readout(x, idx, self.pred.weight, self.pred.bias)   # K9
+        _ops.maybe_check(out.device, "LocalWLNet index")
+        return out
+
+    def _small_graph_ok(self, x, edge1, P):
+        if not (_SMALL_PATH and x.is_cuda and not isinstance(edge1, _ops.CSRGraph)):
+            return False
+        cap = _ops.small_max_rows()
+        convs = list(self.conv1s) + list(self.conv2s) + list(self.conv2s_r)
+        return (0 < x.shape[0] <= cap and 0 < P <= cap and self.emb[0].weight.shape[1] % 4 == 0
+                and len(self.conv2s) == len(self.conv2s_r) >= 1
+                and all(_is_relu_conv(s) and s.modlist[0].in_channels <= 256 for s in convs)
+                and len({s.modlist[1].eps for s in convs}) == 1)
+
+    def _forward_small(self, x, edge1, pos, idx, edge2, edge2_r):
+        """the same forward for graphs of <= 8192 nodes / tuples (the reference's fb-pages-food: 620 / 4252), where
+        the kernel-per-op path is launch-bound: 2 launches per GCN block (linear -> transposed features; aggregation
+        + bias per (feature column, row block) out of LDS), GraphNorm + ReLU deferred into whichever kernel reads
+        the result next, embedding + GraphNorm in one launch, the pair product folded into the first 2-WL linear,
+        both orientations of a 2-WL layer in the same two launches, their sum folded into the next linear / the
+        readout.  21 launches -> 6 at depth 1/1."""
+        N, P = x.shape[0], pos.shape[0]
+        g1 = graph_cache.get(edge1, None, N, True)
+        norm0 = self.emb[1]
+        h = _ops.embedding_graph_norm(self.emb[0].weight, x, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps)
+        for seq in self.conv1s:
+            hT = _ops.small_linear_t(h, seq.modlist[0].lin.weight)
+            h, = _ops.small_gcn(N, [_side(hT, g1, seq)])
+        a = r = None
+        for i, (seq_a, seq_r) in enumerate(zip(self.conv2s, self.conv2s_r)):
+            wa, wr = seq_a.modlist[0].lin.weight, seq_r.modlist[0].lin.weight
+            if i == 0:
+                aT, rT = _ops.small_linear_t(h, wa, wr, pos=pos)               # a6 folded in
+            else:
+                aT, rT = _ops.small_linear_t(a, wa, wr, xb=r)                  # previous layer's a + r folded in
+            a, r = _ops.small_gcn(P, [_side(aT, edge2, seq_a), _side(rT, edge2_r, seq_r)])
+        out = _ops.small_readout(a, r, idx, self.pred.weight, self.pred.bias)
         _ops.maybe_check(out.device, "LocalWLNet index")
         return out
 

@@ -411,6 +411,163 @@ def test_localwl_forward_fb_pages_food(dev, tw, c1, c2, d1, d2):
     assert torch.equal(logits, twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2)))
 
 
+# ------------------------------------------------------------------ small-graph GCN blocks (the launch-bound regime)
+def test_localwl_small_path_matches_generic_path(dev, tw, monkeypatch):
+    """the two-launches-per-block path (default for <= 8192 rows) and the kernel-per-op path agree to fp32
+    rounding on the fb-pages-food forward; each is held to the oracle by test_localwl_forward_fb_pages_food."""
+    from lpgnn_amd import twowl
+    from oracle import twowl_int
+    torch.manual_seed(3)
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
+    ei, pred, ei2 = t(tw["test_ei"]), t(tw["test_pred"]), t(tw["test_ei2"])
+    x_deg = t(twowl_int.degree(tw["val_ei"].astype(np.int64), 620))
+    pos1 = torch.cat([ei.t(), pred.t()], 0).contiguous()
+    for c1, c2, d1, d2 in [(256, 32, 1, 1), (32, 24, 2, 2)]:
+        mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=c1, channels_2wl=c2, depth1=d1, depth2=d2).to(dev).eval()
+        assert mod._small_graph_ok(x_deg, ei, pos1.shape[0])
+        small = twowl.test_forward(mod, x_deg, ei, pos1, pred.shape[1], ei2)
+        monkeypatch.setattr(twowl, "_SMALL_PATH", False)
+        assert not mod._small_graph_ok(x_deg, ei, pos1.shape[0])
+        generic = twowl.test_forward(mod, x_deg, ei, pos1, pred.shape[1], ei2)
+        monkeypatch.setattr(twowl, "_SMALL_PATH", True)
+        scale = float(generic.abs().max()) + 1.0
+        assert float((small - generic).abs().max()) <= 20 * TOL * scale
+
+
+@pytest.mark.parametrize("n,k,m", [(620, 256, 32), (4252, 32, 32), (1, 24, 16), (7, 64, 24), (1030, 100, 40),
+                                    (515, 256, 256)])
+def test_small_linear_t(dev, n, k, m):
+    """(X W^T)^T for the three input forms of lpg_small_linear_t_f32, one and two weight matrices, vs fp64."""
+    from lpgnn_amd import ops
+    rng = np.random.default_rng(n * 7 + k)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32)).to(dev)
+    xa, xb, w, w2 = f(n, k), f(n, k), f(m, k), f(m, k)
+    n_src = max(n // 3, 1)
+    tab = f(n_src, k)
+    pos = torch.from_numpy(rng.integers(0, n_src, size=(n, 2))).to(dev)
+    cases = [(dict(), xa.double()), (dict(xb=xb), xa.double() + xb.double())]
+    for kw, x64 in cases:
+        hT = ops.small_linear_t(xa, w, **kw)
+        assert hT.shape == (m, (n + 3) // 4 * 4)
+        want = (x64 @ w.double().t()).t()
+        mag = (x64.abs() @ w.double().abs().t()).t()
+        assert torch.all((hT[:, :n].double() - want).abs() <= TOL * mag + 1e-30)
+    hT, h2T = ops.small_linear_t(tab, w, w2, pos=pos)
+    x64 = tab.double()[pos[:, 0]] * tab.double()[pos[:, 1]]
+    for got, ww in ((hT, w), (h2T, w2)):
+        want = (x64 @ ww.double().t()).t()
+        mag = (x64.abs() @ ww.double().abs().t()).t()
+        assert torch.all((got[:, :n].double() - want).abs() <= TOL * mag + 1e-30)
+    bad = pos.clone()
+    bad[0, 1] = n_src
+    ops.small_linear_t(tab, w, pos=bad)
+    with pytest.raises(IndexError):
+        ops.raise_if_flagged(torch.device(dev))
+
+
+class _Norm:
+    def __init__(self, rng, c, dev):
+        d = lambda a: torch.from_numpy(a.astype(np.float32)).to(dev)
+        self.weight, self.bias = d(rng.uniform(0.6, 1.4, c)), d(rng.standard_normal(c) * 0.3)
+        self.mean_scale, self.eps = d(rng.uniform(0.6, 1.4, c)), 1e-5
+
+    def ref(self, y, relu):
+        from oracle import aggregation as agg
+        o = agg.graph_norm(y, _np(self.weight).astype(np.float64), _np(self.bias).astype(np.float64),
+                           _np(self.mean_scale).astype(np.float64), self.eps)
+        return np.maximum(o, 0.0) if relu else o
+
+
+@pytest.mark.parametrize("n,E,c,shape,rb", [(620, 3480, 32, "rand", None), (4252, 69525, 24, "hub", None),
+                                             (1, 0, 4, "rand", None), (8192, 200000, 3, "hub", None),
+                                             (300, 0, 5, "rand", 4), (2000, 60000, 2, "star", 8), (37, 5000, 6, "dup", 8),
+                                             (5, 40, 3, "rand", 8), (1000, 30000, 4, "hub", 3)])
+def test_small_gcn_deferred_norm(dev, n, E, c, shape, rb, monkeypatch):
+    """lpg_small_gcn_f32 (A_hat-aggregation + bias per feature column and row block, column-sum partials) and the
+    consumers that apply the deferred GraphNorm + ReLU on load (linear in its three input forms, readout), vs the
+    fp64 restatement of GCNConv / GraphNorm; rows longer than a strip, rows cut by many strip borders (star, hub),
+    empty graphs, duplicate edges, more row blocks than rows, the 8192-row limit; one and two sides per launch;
+    run-to-run bitwise equal."""
+    from lpgnn_amd import ops
+    from lpgnn_amd.nn import graph_cache
+    from oracle import aggregation as agg
+    if rb is not None:
+        monkeypatch.setenv("LPG_SG_ROW_BLOCKS", str(rb))
+    rng = np.random.default_rng(n + E + c)
+    if shape == "star":                       # every edge into row 5: that row spans hundreds of strips
+        ei = np.stack([rng.integers(0, n, size=E), np.full(E, 5)]).astype(np.int64)
+    elif shape == "dup":
+        ei = rng.integers(0, n, size=(2, E)).astype(np.int64)
+    else:
+        ei = rand_graph(rng, n, n, E, hub=0.2 if shape == "hub" else None)
+    ei_t = torch.from_numpy(ei).to(dev)
+    g = graph_cache.get(ei_t, None, n, True)
+    g2 = graph_cache.get(ei_t.flip(0).contiguous(), None, n, True)        # the reversed graph as the second side
+    f = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    h, h2, b1, b2 = f(n, c), f(n, c), f(c) * 0.3, f(c) * 0.3
+    nm1, nm2 = _Norm(rng, c, dev), _Norm(rng, c, dev)
+    ldt = (n + 3) // 4 * 4
+    def tr(a):
+        o = torch.zeros((c, ldt), dtype=torch.float32, device=dev)
+        o[:, :n] = d(a).t()
+        return o
+    sides = [(tr(h), g, d(b1), nm1, True), (tr(h2), g2, d(b2), nm2, False)]
+    one, = ops.small_gcn(n, sides[:1])
+    a, r = ops.small_gcn(n, sides)
+    a2, r2 = ops.small_gcn(n, sides)
+    assert torch.equal(one.y, a.y) and torch.equal(one.part, a.part)
+    assert torch.equal(a.y, a2.y) and torch.equal(r.y, r2.y) and torch.equal(a.part, a2.part) and torch.equal(r.part, r2.part)
+    eye = np.eye(c)
+    ya = agg.gcn_conv(h.astype(np.float64), ei, eye, b1.astype(np.float64))
+    yr = agg.gcn_conv(h2.astype(np.float64), np.ascontiguousarray(ei[::-1]), eye, b2.astype(np.float64))
+    for got, want in ((a, ya), (r, yr)):
+        assert np.abs(_np(got.y) - want).max() <= 20 * TOL * (np.abs(want).max() + 1.0)
+        assert np.allclose(_np(got.part[:, 0].sum(0)), want.sum(0), rtol=1e-5, atol=1e-4)
+        assert np.allclose(_np(got.part[:, 1].sum(0)), (want * want).sum(0), rtol=1e-4, atol=1e-4)
+    xa64, xr64 = nm1.ref(ya, True), nm2.ref(yr, False)
+    tol = lambda want: 50 * TOL * (np.abs(want).max() + 1.0)
+    assert np.abs(_np(a.materialize()) - xa64).max() <= tol(xa64)
+    # consumers: linear (plain / pair / sum), readout
+    m = 7
+    w, w2 = f(m, c), f(m, c)
+    hT = ops.small_linear_t(a, d(w))
+    want = (xa64 @ w.astype(np.float64).T).T
+    assert np.abs(_np(hT[:, :n]) - want).max() <= tol(want) * c
+    hT, h2T = ops.small_linear_t(a, d(w), d(w2), xb=r)
+    for got, ww in ((hT, w), (h2T, w2)):
+        want = ((xa64 + xr64) @ ww.astype(np.float64).T).T
+        assert np.abs(_np(got[:, :n]) - want).max() <= tol(want) * c
+    npair = 2 * n + 3
+    pos = rng.integers(0, n, size=(npair, 2))
+    hT = ops.small_linear_t(a, d(w), pos=d(pos))
+    want = ((xa64[pos[:, 0]] * xa64[pos[:, 1]]) @ w.astype(np.float64).T).T
+    assert np.abs(_np(hT[:, :npair]) - want).max() <= tol(want) * c
+    idx = rng.integers(0, n, size=2 * 50)
+    pw, pb = f(1, c), f(1)
+    for rr, x64 in ((r, xa64 + xr64), (None, xa64)):
+        got = ops.small_readout(a, rr, d(idx), d(pw), d(pb))
+        want = agg.pair_readout(x64, idx, pw.astype(np.float64), pb.astype(np.float64))
+        assert got.shape == (50, 1) and np.abs(_np(got) - want).max() <= tol(want) * c
+
+
+def test_embedding_graph_norm(dev):
+    from lpgnn_amd import ops
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(12)
+    for n, rows, dch in [(620, 135, 256), (1, 3, 4), (8192, 50, 24)]:
+        tab = rng.standard_normal((rows, dch)).astype(np.float32)
+        idx = rng.integers(0, rows, size=n)
+        gw, gb, gms = (rng.uniform(0.6, 1.4, dch).astype(np.float32), rng.standard_normal(dch).astype(np.float32),
+                       rng.uniform(0.6, 1.4, dch).astype(np.float32))
+        d = lambda a: torch.from_numpy(a).to(dev)
+        got = ops.embedding_graph_norm(d(tab), d(idx), d(gw), d(gb), d(gms))
+        two = ops.graph_norm(ops.embedding(d(tab), d(idx)), d(gw), d(gb), d(gms))
+        assert torch.equal(got, two)                      # same kernel, gather folded in
+        want = agg.graph_norm(tab[idx].astype(np.float64), gw.astype(np.float64), gb.astype(np.float64), gms.astype(np.float64))
+        assert np.abs(_np(got) - want).max() <= 20 * TOL * (np.abs(want).max() + 1.0)
+
+
 # ------------------------------------------------------------------ SEAL structure path vs the reference's goldens
 @pytest.fixture(scope="module")
 def sl(golden_dir):
