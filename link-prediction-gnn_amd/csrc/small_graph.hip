@@ -114,11 +114,14 @@ __device__ __forceinline__ float sg_apply(const SgCoef& c, float y) {
 }
 
 // ------------------------------------------------------------------------------------------------ linear
-// A wave owns 4 consecutive rows; lane l holds the contraction indices l, l + 64, ... (KPL of them), so a row
-// is one coalesced load per 64 values.  Outputs are produced 16 at a time: every lane forms its partial dot
-// products with the 16 weight rows, then a halving butterfly (8 + 4 + 2 + 1 + 2 shuffles instead of 16 x 6)
-// leaves output (lane >> 2) summed over all lanes; one lane in four stores the 4 rows as one 16-byte piece of the
-// transposed output.
+// Outputs across lanes: a workgroup (4 waves x 4 rows) stages a tile of up to 64 weight rows TRANSPOSED in LDS
+// ([k][64 + 1]: conflict-free for "lanes = outputs") and its 16 input rows (normalised / multiplied / added
+// while loading) as plain rows; then lane s owns output s and walks k: the input value is one LDS broadcast per
+// 4 k's and 4 rows, the weight one conflict-free read, and NO cross-lane reduction exists (the first version
+// spread k over the lanes and spent its time in 272 dependent shuffles per 4 rows).  With fewer than 64 output
+// slots per workgroup (8..32: long k, few outputs) the 64 / slots lane groups split k and meet in 1-3 shuffles;
+// the grid is (row tiles) x (output tiles).  A lane ends with its output for 4 consecutive rows = one 16-byte
+// piece of the transposed result.
 struct SgLinArgs {
   const float* xa;       // mode 0: rows [n, k]; mode 1: table [n_src, k]; mode 2: first addend [n, k]
   const float* xb;       // mode 2: second addend
@@ -128,55 +131,34 @@ struct SgLinArgs {
   float* hT;             // [m, ldt]
   float* h2T;            // [m, ldt] or null
   int32_t* err_flag;
-  int n, n_src, k, m, mode;
+  int n, n_src, k, m, mode, slots;
   int64_t ldt;
   SgNorm na, nb;         // deferred GraphNorm of xa / xb
 };
 
-// one halving step of the butterfly: lanes with bit OFF keep the upper HALF partials and hand over the lower ones
-template <int HALF, int OFF>
-__device__ __forceinline__ void sg_halve(float (&p)[16], int lane) {
-  const bool up = (lane & OFF) != 0;
-#pragma unroll
-  for (int q = 0; q < HALF; ++q) {
-    const float keep = up ? p[q + HALF] : p[q];
-    const float send = up ? p[q] : p[q + HALF];
-    p[q] = keep + __shfl_xor(send, OFF, 64);
-  }
-}
+constexpr int kSgLinK = 256;            // largest contraction length
+constexpr int kSgLinRows = 16;          // rows per workgroup (4 waves x 4)
+constexpr int kSgWtLd = 65;             // padded leading dimension of the transposed weight tile
 
-template <int KPL>
-__device__ __forceinline__ void sg_load_w(const SgLinArgs& a, int pass, int tiles, int lane, float (&dst)[16][KPL]) {
-  const float* __restrict__ w = pass >= tiles ? a.w2 : a.w;
-  const int tile = pass >= tiles ? pass - tiles : pass;
-#pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    const int oo = tile * 16 + o < a.m ? tile * 16 + o : a.m - 1;
-#pragma unroll
-    for (int j = 0; j < KPL; ++j) {
-      const int kk = lane + 64 * j;
-      dst[o][j] = w[oo * a.k + (kk < a.k ? kk : a.k - 1)];
-    }
-  }
-}
-
-template <int KPL>
+template <int KPL>                       // ceil(k / 64): input values per lane while staging a row
 __global__ __launch_bounds__(kBlock) void sg_linear_t_kernel(const SgLinArgs a) {
-  constexpr int TO = 16;                                   // outputs per pass: TO * KPL weight registers
-  const int lane = threadIdx.x & 63;
-  const int group = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-  const int r0 = group * 4;
-  if (r0 >= a.n) return;                                   // wave-uniform
-  const int tiles = (a.m + TO - 1) / TO;
-  const int passes = a.w2 ? 2 * tiles : tiles;
-  // weights of pass 0 are requested before anything else; pass p + 1 is requested before pass p is consumed
-  float wf[TO][KPL], wn[TO][KPL];
-  sg_load_w<KPL>(a, 0, tiles, lane, wf);
-  float x[4][KPL];
+  extern __shared__ __attribute__((aligned(16))) float sg_lds[];     // sized by k: small k => several workgroups per CU
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r0 = (blockIdx.x * (kBlock / kWave) + wv) * 4;
+  const int kpad = (a.k + 3) & ~3;
+  float* __restrict__ xs = sg_lds;                          // [16][kpad]
+  float* __restrict__ wt = sg_lds + kSgLinRows * kpad;      // [kpad][65]
+  const int m_total = a.w2 ? 2 * a.m : a.m;
+  const int SL = a.slots;                                  // output slots of a workgroup (8..64); blockIdx.y = output tile
+  const int kparts = 64 / SL;
+  // ---- the wave's 4 input rows -> LDS (lane = k index, KPL = ceil(k / 64) steps)
   {
     int64_t ra[4], rb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = rb[i] = r0 + i < a.n ? r0 + i : a.n - 1;   // clamped rows: finite duplicates, stored into padding
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + i < a.n ? r0 + i : a.n - 1;       // clamped rows: finite duplicates, stored into padding
+      ra[i] = rb[i] = r;
+    }
     if (a.mode == 1) {
       int64_t p0[4], p1[4];
 #pragma unroll
@@ -194,16 +176,18 @@ __global__ __launch_bounds__(kBlock) void sg_linear_t_kernel(const SgLinArgs a) 
       }
       if (bad && lane == 0) flag_error(a.err_flag, LPG_F_INDEX_RANGE);
     }
-    float u[4][KPL], v[4][KPL];
+    // every load of the 4 rows first (clamped), then the arithmetic
+    float u[KPL][4], v[KPL][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < KPL; ++j) {
+      const int kk = lane + 64 * j;
+      const int kc = kk < a.k ? kk : a.k - 1;
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) {
-        const int kk = lane + 64 * j;
-        const int kc = kk < a.k ? kk : a.k - 1;            // unconditional clamped loads, selects afterwards
-        u[i][j] = a.xa[ra[i] * a.k + kc];
-        v[i][j] = a.mode == 0 ? 0.f : (a.mode == 1 ? a.xa[rb[i] * a.k + kc] : a.xb[rb[i] * a.k + kc]);
+      for (int i = 0; i < 4; ++i) {
+        u[j][i] = a.xa[ra[i] * a.k + kc];
+        v[j][i] = a.mode == 0 ? 0.f : (a.mode == 1 ? a.xa[rb[i] * a.k + kc] : a.xb[rb[i] * a.k + kc]);
       }
+    }
     SgCoef ca[KPL], cb[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
@@ -212,47 +196,72 @@ __global__ __launch_bounds__(kBlock) void sg_linear_t_kernel(const SgLinArgs a) 
       ca[j] = sg_coef(a.na, kc);
       cb[j] = a.mode == 2 ? sg_coef(a.nb, kc) : ca[j];
     }
-    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < KPL; ++j) {
+      const int kk = lane + 64 * j;
+      if (kk < kpad) {
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) {
-        const float fu = sg_apply(ca[j], u[i][j]), fv = sg_apply(cb[j], v[i][j]);
-        const float t = a.mode == 0 ? fu : (a.mode == 1 ? fu * fv : fu + fv);
-        x[i][j] = lane + 64 * j < a.k ? t : 0.f;
+        for (int i = 0; i < 4; ++i) {
+          const float fu = sg_apply(ca[j], u[j][i]), fv = sg_apply(cb[j], v[j][i]);
+          const float t = a.mode == 0 ? fu : (a.mode == 1 ? fu * fv : fu + fv);
+          xs[(wv * 4 + i) * kpad + kk] = kk < a.k ? t : 0.f;         // zero tail up to a multiple of 4
+        }
       }
-  }
-  for (int pass = 0; pass < passes; ++pass) {
-    if (pass + 1 < passes) sg_load_w<KPL>(a, pass + 1, tiles, lane, wn);
-    float* __restrict__ out = pass >= tiles ? a.h2T : a.hT;
-    const int tile = pass >= tiles ? pass - tiles : pass;
-    float res[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float p[TO];
-#pragma unroll
-      for (int o = 0; o < TO; ++o) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) s = fmaf(x[i][j], wf[o][j], s);     // x is 0 beyond k: clamped w is harmless
-        p[o] = s;
-      }
-      sg_halve<8, 32>(p, lane);                        // compile-time steps: p stays in registers
-      sg_halve<4, 16>(p, lane);
-      sg_halve<2, 8>(p, lane);
-      sg_halve<1, 4>(p, lane);
-      p[0] += __shfl_xor(p[0], 2, 64);
-      res[i] = p[0] + __shfl_xor(p[0], 1, 64);
-      __builtin_amdgcn_sched_barrier(0);               // one row's partials at a time (else the rows interleave and spill)
     }
-    const int o = tile * TO + (lane >> 2);
-    if ((lane & 3) == 0 && o < a.m)
-      *reinterpret_cast<float4*>(out + static_cast<int64_t>(o) * a.ldt + r0) = make_float4(res[0], res[1], res[2], res[3]);
-    if (pass + 1 < passes) {
+  }
+  const int s = lane & (SL - 1), kp = lane / SL;
+  const int kh = kparts == 1 ? kpad : (((kpad + kparts - 1) / kparts + 3) & ~3);     // k's per lane group, a multiple of 4
+  const int k_lo = kp * kh, k_hi = (k_lo + kh < kpad) ? k_lo + kh : kpad;
+  {
+    const int g0 = blockIdx.y * SL;
+    // ---- stage the weight tile transposed: element e = slot * kpad + kk (kk fastest: coalesced reads)
+    const int total = SL * kpad;
+    const int d_sl = kBlock / kpad, d_kk = kBlock - d_sl * kpad;       // one step of 256 elements in (slot, k)
+    int sl = tid / kpad, kk = tid - sl * kpad;
+    for (int e0 = 0; e0 < total; e0 += kBlock * 8) {
+      float wv8[8];
+      int sl8[8], kk8[8];
 #pragma unroll
-      for (int o2 = 0; o2 < TO; ++o2)
+      for (int q = 0; q < 8; ++q) {
+        sl8[q] = sl; kk8[q] = kk;
+        int g = g0 + sl;
+        g = g < m_total ? g : m_total - 1;
+        const float* __restrict__ wm = g >= a.m ? a.w2 : a.w;
+        const int o = g >= a.m ? g - a.m : g;
+        wv8[q] = wm[o * a.k + (kk < a.k ? kk : a.k - 1)];
+        sl += d_sl; kk += d_kk;
+        if (kk >= kpad) { kk -= kpad; ++sl; }
+      }
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) wf[o2][j] = wn[o2][j];
+      for (int q = 0; q < 8; ++q)
+        if (sl8[q] < SL) wt[kk8[q] * kSgWtLd + sl8[q]] = kk8[q] < a.k ? wv8[q] : 0.f;
+    }
+    __syncthreads();
+    // ---- lane = output slot: walk k
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = k_lo; kk < k_hi; kk += 4) {
+      float4 xv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4*>(&xs[(wv * 4 + i) * kpad + kk]);
+      const float w0 = wt[(kk + 0) * kSgWtLd + s], w1 = wt[(kk + 1) * kSgWtLd + s], w2 = wt[(kk + 2) * kSgWtLd + s],
+                  w3 = wt[(kk + 3) * kSgWtLd + s];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = fmaf(xv[i].x, w0, acc[i]);
+        acc[i] = fmaf(xv[i].y, w1, acc[i]);
+        acc[i] = fmaf(xv[i].z, w2, acc[i]);
+        acc[i] = fmaf(xv[i].w, w3, acc[i]);
+      }
+    }
+    for (int o = 32; o >= SL; o >>= 1) {                   // the lane groups that split k meet
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    const int g = g0 + s;
+    if (kp == 0 && g < m_total && r0 < a.n) {
+      float* __restrict__ out = g >= a.m ? a.h2T : a.hT;
+      const int o = g >= a.m ? g - a.m : g;
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(o) * a.ldt + r0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
   }
 }
@@ -284,6 +293,13 @@ __global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const
   const int64_t e0 = s.rowptr[r0], e1 = s.rowptr[r1];
   const float bias = s.bias ? s.bias[c] : 0.f;
   const uint4* __restrict__ pk = reinterpret_cast<const uint4*>(s.pack + static_cast<int64_t>(blk) * cap_words);
+  // the first strip steps are requested before the strip length is known (a dependent round trip less); steps
+  // beyond it hold stale words of the capacity-sized buffer and are masked by `live` below
+  constexpr int kBatch = 6;
+  const int q_cap = static_cast<int>(cap_words / (kSgBlock * 4));
+  uint4 u[kBatch], un[kBatch];
+#pragma unroll
+  for (int b = 0; b < kBatch; ++b) u[b] = pk[static_cast<int64_t>(b < q_cap ? b : q_cap - 1) * kSgBlock + t];
   float dv[kSgRowsPerThread];
   {
     float hv[kSgRowsPerThread], dd[kSgRowsPerThread];
@@ -304,10 +320,6 @@ __global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const
     }
   }
   const int Q = static_cast<int>(sg_strip(e1 - e0) >> 2);   // 16-byte steps of a strip
-  constexpr int kBatch = 6;
-  uint4 u[kBatch], un[kBatch];
-#pragma unroll
-  for (int b = 0; b < kBatch; ++b) u[b] = pk[static_cast<int64_t>(b < Q ? b : Q - 1) * kSgBlock + t];
   __syncthreads();
 
   // ---- strip walk: the loads of step group b + 1 are in flight while group b is walked
@@ -485,7 +497,7 @@ LPG_EXPORT int lpg_small_linear_t_f32(const float* xa, const float* xb, const in
                                       int relu_a, const double* part_b, const float* gn_weight_b, const float* gn_bias_b,
                                       const float* gn_mean_scale_b, int64_t row_blocks_b, int relu_b, float eps,
                                       int32_t* err_flag, void* stream) {
-  LPG_REQUIRE(n >= 0 && k >= 1 && k <= 256 && m >= 1 && mode >= 0 && mode <= 2, "small_linear_t: bad sizes (k <= 256)");
+  LPG_REQUIRE(n >= 0 && k >= 1 && k <= kSgLinK && m >= 1 && mode >= 0 && mode <= 2, "small_linear_t: bad sizes (k <= %d)", kSgLinK);
   if (n == 0) return LPG_OK;
   LPG_REQUIRE(n <= (int64_t(1) << 30) && xa && w && hT && (!w2 || h2T), "small_linear_t: null pointer");
   LPG_REQUIRE((mode != 1 || (pos && n_src >= 1)) && (mode != 2 || xb), "small_linear_t: mode operand missing");
@@ -499,15 +511,30 @@ LPG_EXPORT int lpg_small_linear_t_f32(const float* xa, const float* xb, const in
   LPG_REQUIRE(make_norm(&a.na, part_a, gn_weight_a, gn_bias_a, gn_mean_scale_a, row_blocks_a, relu_a, n_stat, k, eps) &&
               make_norm(&a.nb, part_b, gn_weight_b, gn_bias_b, gn_mean_scale_b, row_blocks_b, relu_b, n_stat, k, eps),
               "small_linear_t: bad deferred-norm descriptor");
-  const int64_t groups = ceil_div(n, 4);
-  const dim3 grid(static_cast<unsigned>(ceil_div(groups, kBlock / kWave))), blk(kBlock);
+  const int64_t kpad = (k + 3) & ~int64_t(3);
+  // output slots per workgroup: the transposed weight tile (slots x kpad) is staged in ONE batch of 8 loads per
+  // thread when it has <= 2048 elements; fewer slots = more workgroups, each lane group walking a shorter piece of k
+  const int64_t m_total = w2 ? 2 * m : m;
+  int slots = 64;
+  while (slots > 8 && (slots * kpad > 2048 || slots / 2 >= m_total)) slots >>= 1;
+  a.slots = slots;
+  const size_t lds = static_cast<size_t>(kSgLinRows * kpad + kpad * kSgWtLd) * sizeof(float);   // <= 83 KB
+  const dim3 grid(static_cast<unsigned>(ceil_div(n, kSgLinRows)), static_cast<unsigned>(ceil_div(m_total, slots)));
   hipStream_t st = as_stream(stream);
+#define LPG_SG_LIN(KPLV)                                                                                             \
+  do {                                                                                                               \
+    static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(sg_linear_t_kernel<KPLV>),     \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);      \
+    LPG_REQUIRE(optin == hipSuccess, "small_linear_t: cannot reserve dynamic LDS");                                  \
+    hipLaunchKernelGGL(sg_linear_t_kernel<KPLV>, grid, dim3(kBlock), lds, st, a);                                    \
+  } while (0)
   switch ((k + 63) / 64) {
-    case 1: hipLaunchKernelGGL(sg_linear_t_kernel<1>, grid, blk, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(sg_linear_t_kernel<2>, grid, blk, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(sg_linear_t_kernel<3>, grid, blk, 0, st, a); break;
-    default: hipLaunchKernelGGL(sg_linear_t_kernel<4>, grid, blk, 0, st, a); break;
+    case 1: LPG_SG_LIN(1); break;
+    case 2: LPG_SG_LIN(2); break;
+    case 3: LPG_SG_LIN(3); break;
+    default: LPG_SG_LIN(4); break;
   }
+#undef LPG_SG_LIN
   return check_launch("small_linear_t");
 }
 
