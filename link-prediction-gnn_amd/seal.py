@@ -376,8 +376,10 @@ def head(z, key, node_off, hw):
     fw, c1, c2 = hw["conv1d_kernel_2"].shape
     k = hw["weight_1"].shape[0] // c2 + fw - 1                                           # threshold_k (18)
     B = node_off.numel() - 1
-    pooled = sortpool(z, key, node_off, k)                                               # [B, k, 96]
-    a = _ops.linear(pooled.view(B * k, -1), k1, w_is_km=True)                            # [B*k, 16]
+    # conv1d #1 is a per-vertex linear (stride = filter width = one 96-wide row) with no activation, and SortPooling
+    # only gathers rows (zero rows stay zero): conv1d(sortpool(z)) == sortpool(z @ k1) value for value.  Multiplying
+    # first moves 16-float rows through the pooling instead of 96-float ones (1.25 GB less traffic per 100 K subgraphs).
+    a = sortpool(_ops.linear(z, k1, w_is_km=True), key, node_off, k).view(B * k, -1)      # [B*k, 16]
     # rows t >= k - fw + 1 of a subgraph's block are windows that run into the next subgraph; the dense layer below
     # reads only the first (k - fw + 1) * c2 values of each block, so they (and the unwritten tail) are never used
     c = torch.empty((B * k, c2), dtype=torch.float32, device=z.device)
