@@ -111,7 +111,8 @@ __device__ ListPlan truncated_list(int32_t node, int64_t deg, int m, uint64_t h)
 __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void seal_subgraph_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_graph, const int64_t* __restrict__ pairs,
     int64_t B, int hop, int max_nb, int replay, int cap_policy, uint64_t seed, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
-    int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag) {
+    int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag,
+    uint8_t* __restrict__ tag_present) {
   __shared__ int32_t cand[2 * MAXN];
   __shared__ int32_t nodes[MAXN];
   __shared__ uint32_t adj[MAXN][WORDS];
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
         }
       }
       tags_out[b * MAXN + t] = tag;
+      if (tag_present && tag >= 0) tag_present[tag] = 1;      // presence table for the global tag compaction (same value from every writer)
       if (!replay) nodes_out[b * MAXN + t] = nd;
 #pragma unroll
       for (int w = 0; w < WORDS; ++w) adj_out[(b * MAXN + t) * WORDS + w] = t < n ? adj[t][w] : 0u;
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(kBlock) void softmax2_kernel(const float* __restric
 LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
                                   const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
                                   int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits, uint8_t* capped,
-                                  int32_t* err_flag, void* stream) {
+                                  uint8_t* tag_present, int32_t* err_flag, void* stream) {
   LPG_REQUIRE(B >= 0 && n_graph_nodes >= 0, "seal_subgraphs: bad sizes");
   LPG_REQUIRE(hop == 0 || hop == 1, "seal_subgraphs: hop must be 0 or 1 (the reference itself fails for hop >= 2)");
   LPG_REQUIRE(max_neighbors >= 2 && max_neighbors <= MAXN, "seal_subgraphs: max_neighbors must be in [2, %d]", MAXN);
@@ -691,7 +693,8 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   LPG_REQUIRE(adj_rowptr && pairs && nodes && n_nodes && tags && adj_bits && capped, "seal_subgraphs: null pointer");
   const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
   hipLaunchKernelGGL(seal_subgraph_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), adj_rowptr, adj_col,
-                     n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag);
+                     n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag,
+                     tag_present);
   return check_launch("seal_subgraphs");
 }
 

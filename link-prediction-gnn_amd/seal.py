@@ -43,8 +43,9 @@ def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
 
 
 class SubgraphBatch:
-    def __init__(self, pairs, nodes, n, tags, adj_bits, capped):
+    def __init__(self, pairs, nodes, n, tags, adj_bits, capped, tag_present=None):
         self.pairs, self.nodes, self.n, self.tags, self.adj_bits, self.capped = pairs, nodes, n, tags, adj_bits, capped
+        self.tag_present = tag_present            # uint8 [TAG_BOUND + 1], byte [tag] set by the extraction kernel
         self.B = pairs.shape[0]
         self._off = None
         self._total = None
@@ -92,13 +93,14 @@ def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, r
     tags = torch.empty((B, MAXN), dtype=torch.int32, device=dev)
     adj_bits = torch.empty((B, MAXN, MAXN // 32), dtype=torch.int32, device=dev)
     capped = torch.empty(B, dtype=torch.uint8, device=dev)
+    present = torch.zeros(_TAG_BOUND + 1, dtype=torch.uint8, device=dev)
     _lib.check(lib.lpg_seal_subgraphs(_ops._ptr(graph.rowptr), _ops._ptr(graph.col), graph.n_nodes, _ops._ptr(pairs),
                                       B, int(hop), int(max_neighbors), int(replay), CAP_POLICY[cap_policy],
                                       int(seed) & 0xFFFFFFFFFFFFFFFF, _ops._ptr(nodes), _ops._ptr(n),
-                                      _ops._ptr(tags), _ops._ptr(adj_bits), _ops._ptr(capped),
+                                      _ops._ptr(tags), _ops._ptr(adj_bits), _ops._ptr(capped), _ops._ptr(present),
                                       _ops._ptr(_ops.err_flag(dev)), _ops._stream()), "seal_subgraphs")
     _ops.maybe_check(dev, "candidate pair / node id")
-    return SubgraphBatch(pairs, nodes, n, tags, adj_bits, capped)
+    return SubgraphBatch(pairs, nodes, n, tags, adj_bits, capped, present)
 
 
 def _host_capped_nodes(pair, rowptr, col, max_neighbors, rng):
@@ -201,6 +203,7 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
                                     replay_n=np.asarray([len(l) for l in lists], dtype=np.int32))
             ii = torch.as_tensor(idx, device=batch.n.device)
             batch.nodes[ii], batch.n[ii], batch.tags[ii], batch.adj_bits[ii] = sub.nodes, sub.n, sub.tags, sub.adj_bits
+            batch.tag_present |= sub.tag_present          # capped pairs came back with n = 0 (no tags) the first time
             batch._off = batch._total = None                   # the sizes changed
     labels = torch.cat([torch.zeros(len(negative), dtype=torch.uint8), torch.ones(len(positive), dtype=torch.uint8)])
     tag_map, tags_size = compact_tag_map(batch)
@@ -217,9 +220,12 @@ def compact_tag_map(batch):
     # presence table instead of a sort-based unique over [B, 128] tags (0.32 -> 0.1 ms for 100 K pairs): a DRNL
     # tag on <= 128 vertices is at most 1 + 127 + 127 * 127; slot 0 takes the -1 padding
     dev = batch.tags.device
-    present = torch.zeros(_TAG_BOUND + 2, dtype=torch.uint8, device=dev)
-    present[batch.tags.reshape(-1).long() + 1] = 1
-    uniq = torch.nonzero(present[1:]).flatten()              # ascending tags (one host sync, as before)
+    if batch.tag_present is not None:                        # filled by the extraction kernel as it wrote the tags
+        uniq = torch.nonzero(batch.tag_present).flatten()    # ascending tags (one host sync, as before)
+    else:
+        present = torch.zeros(_TAG_BOUND + 2, dtype=torch.uint8, device=dev)
+        present[batch.tags.reshape(-1).long() + 1] = 1
+        uniq = torch.nonzero(present[1:]).flatten()
     T = int(uniq.numel())
     tag_map = torch.full((int(uniq.max().item()) + 1 if T else 1,), -1, dtype=torch.int32, device=batch.tags.device)
     tag_map[uniq.long()] = torch.arange(T, dtype=torch.int32, device=batch.tags.device)
