@@ -634,10 +634,15 @@ __global__ __launch_bounds__(kSealBlock) void seal_sortpool_kernel(const float* 
     __syncthreads();
     if (t < n) {
       const float mine = keys[t];
+      const bool mine_nan = mine != mine;
       int rank = 0;                // number of vertices that come before t: larger key, or equal key and lower index
       for (int j = 0; j < n; ++j) {
         const float o = keys[j];
-        rank += (o > mine) || (o == mine && j < t);
+        // a TOTAL order even with NaN keys (NaN sorts last, ties by index): ranks must stay a permutation, `order`
+        // indexes global memory below (a NaN key once made two threads claim rank 0 and left slots unwritten)
+        const bool o_nan = o != o;
+        const bool tie = (o == mine) || (o_nan && mine_nan);
+        rank += (o > mine) || (mine_nan && !o_nan) || (tie && j < t);
       }
       order[rank] = t;
     }

@@ -850,6 +850,11 @@ def test_seal_head_with_reference_weights(dev, sl, golden_dir):
     kt = torch.tensor([1.0, 3.0, 3.0, 0.5, 3.0, 2.0], device=dev)
     p = seal.sortpool(zt, kt, torch.tensor([0, 6], device=dev), 4)
     assert _np(p)[0, :, 0].tolist() == [2.0, 4.0, 8.0, 10.0]
+    # NaN keys (a NaN in a caller's embedding ends up here): still a permutation -- NaN last, ties by index -- and
+    # never an out-of-range gather
+    kn = torch.tensor([float("nan"), 3.0, float("nan"), 0.5, 3.0, 2.0], device=dev)
+    p = seal.sortpool(zt, kn, torch.tensor([0, 6], device=dev), 6)
+    assert _np(p)[0, :, 0].tolist() == [2.0, 8.0, 10.0, 6.0, 0.0, 4.0]
     # end-to-end scoring entry point
     s2, lab, _ = seal.score_links(pos, neg, 620, emb, gw, hw, device=dev)
     assert torch.equal(s2, score)
