@@ -19,18 +19,42 @@
 // and the block-diagonal CSR, its plan, three SpMMs + fix-ups, three small linears and the d = 1 SpMM of the
 // generic path are not needed at all.  Summation order differs from the CSR path (a zero-padded dense product
 // in MFMA order instead of ascending neighbours): deterministic, and within 1e-6 of it.
+#include <stdlib.h>
+
 #include "lpg_common.hpp"
 
 namespace {
 using namespace lpg;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+
+// ---- the aggregation on the BF16 matrix cores, exactly -------------------------------------------------------
+// (A + I) has entries 0 / 1 / 2: exact in bf16.  An fp32 value splits exactly into three bf16 terms (8 + 8 + 8
+// mantissa bits: hi = the top 16 bits, mid = the top 16 bits of v - hi, lo = v - hi - mid).  So
+//   (A + I) H = (A + I) H_hi + (A + I) H_mid + (A + I) H_lo
+// with every product exact and the sums in the MFMA's fp32 accumulator: the same arithmetic class as the fp32
+// matrix-core product, on v_mfma_f32_32x32x16_bf16 -- 6 MFMAs of 32 cycles per 32 x 32 block instead of 16
+// v_mfma_f32_32x32x2_f32 of 64 cycles (the aggregation loop was 0.66 of this kernel's 1.2 ms, serial MFMA chains).
+// D^-1 is a row scale applied to the accumulator before tanh.  H lives in LDS as three TRANSPOSED bf16 planes
+// ([plane][feature][row]: the B operand's 8 consecutive k = 8 consecutive rows of one feature is one 16-byte read);
+// the A operand (8 consecutive bits of the row's adjacency window) comes from a 256-entry byte -> 8 x bf16 table.
 
 constexpr int MAXN = LPG_SEAL_MAXN;   // 128
 constexpr int WORDS = MAXN / 32;
 constexpr int WIN = 128;              // a workgroup owns the subgraphs that start in a 128-row window
 constexpr int RMAX = WIN + MAXN;      // rows it can end up with (<= 255), rounded to tiles of 32
 constexpr int kConvBlock = 256;       // 4 waves, up to two 32-row tiles each (a workgroup has at most 8)
+constexpr int HS = 256 + 8;           // row stride of a transposed bf16 plane (528 B: 16-byte aligned, 4 banks apart)
+
+// exact three-way split of an fp32 value into bf16 terms (truncations; each remainder is exact in fp32)
+__device__ __forceinline__ void split3(float v, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const uint32_t uh = __float_as_uint(v) & 0xFFFF0000u;
+  const float r1 = v - __uint_as_float(uh);
+  const uint32_t um = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(um);
+  hi = uh >> 16; mid = um >> 16; lo = __float_as_uint(r2) >> 16;
+}
 
 // tanh(v) = 1 - 2 / (exp(2 v) + 1) with the hardware reciprocal (1 ulp): |error| < 3e-7 absolute on an output in
 // [-1, 1], branch-free; saturates cleanly (exp -> inf gives 1, exp -> 0 gives -1).
@@ -43,11 +67,15 @@ struct RowCtx {
   uint32_t b0, b1, b2, b3;   // the row's adjacency bits
 };
 
+template <bool SPLIT>          // SPLIT: aggregation on the bf16 matrix cores (exact three-way split), else fp32 MFMA
 __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
     const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
     const float* __restrict__ h1, int64_t ldh, const float* __restrict__ w2, const float* __restrict__ w3,
     const float* __restrict__ w4, float* __restrict__ cat, int64_t ldc, float* __restrict__ key) {
-  __shared__ float H[RMAX][32];                     // 32 KB: the current layer's H rows of the owned subgraphs
+  __shared__ __attribute__((aligned(16))) float H[SPLIT ? 1 : RMAX][32];          // fp32 path: the current layer's H rows
+  __shared__ __attribute__((aligned(16))) uint16_t Hp[SPLIT ? 3 : 1][SPLIT ? 32 : 1][SPLIT ? HS : 8];   // bf16 planes, transposed
+  __shared__ __attribute__((aligned(16))) uint4 lut[SPLIT ? 256 : 1];            // byte -> 8 x bf16 {0, 1}
+  __shared__ __attribute__((aligned(16))) float dinvs[SPLIT ? RMAX : 4];         // D^-1 per local row
   __shared__ uint32_t rinfo[RMAX];                  // per local row: (local subgraph index << 8) | vertex index
   __shared__ uint32_t rbits[RMAX][WORDS];           // its adjacency row
   __shared__ int soff[WIN + 2];                     // local row offset of each owned subgraph
@@ -59,6 +87,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
   const int nsub = bl - bf;                         // <= 128: every owned subgraph starts in the window
   const int64_t r_lo = node_off[bf];
   const int nrows = static_cast<int>(node_off[bl] - r_lo);
+  const int ntiles = (nrows + 31) >> 5;             // <= 8
 
   // the loads that depend on nothing but the window come first: they fly during the index work below
   // W_{l+1} in the B-operand layout: lane (n = r, h) holds W[k = 2 s + h][n] for s = 0..15
@@ -69,21 +98,47 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
     Wb3[s] = w3[(2 * s + h) * 32 + r];
     Wb4[s] = r == 0 ? w4[2 * s + h] : 0.f;          // 32 -> 1 as a 32 x 32 product whose column 0 is the result
   }
-  for (int idx = tid; idx < nrows * 32; idx += kConvBlock) H[idx >> 5][idx & 31] = h1[(r_lo + (idx >> 5)) * ldh + (idx & 31)];
+  if constexpr (SPLIT) {
+    // H_1 -> three transposed bf16 planes; rows [nrows, 32 ntiles) are zero (their A entries are zero, but 0 x NaN is not)
+    for (int idx = tid; idx < ntiles * 32 * 32; idx += kConvBlock) {
+      const int row = idx >> 5, c = idx & 31;
+      const float v = row < nrows ? h1[(r_lo + row) * ldh + c] : 0.f;
+      uint32_t a0, a1, a2;
+      split3(v, a0, a1, a2);
+      Hp[0][c][row] = static_cast<uint16_t>(a0);
+      Hp[1][c][row] = static_cast<uint16_t>(a1);
+      Hp[2][c][row] = static_cast<uint16_t>(a2);
+    }
+    {                                               // byte -> 8 bf16 (bit j set -> 1.0 = 0x3F80 in element j)
+      uint32_t d[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        d[q] = (((tid >> (2 * q)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * q + 1)) & 1) ? 0x3F800000u : 0u);
+      lut[tid] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+  } else {
+    for (int idx = tid; idx < nrows * 32; idx += kConvBlock) H[idx >> 5][idx & 31] = h1[(r_lo + (idx >> 5)) * ldh + (idx & 31)];
+  }
   // ---- per-subgraph offsets, per-row (subgraph, vertex) and adjacency rows
   for (int q = tid; q <= nsub; q += kConvBlock) soff[q] = static_cast<int>(node_off[bf + q] - r_lo);
   __syncthreads();
   for (int q = tid; q < nsub; q += kConvBlock)
     for (int lr = soff[q]; lr < soff[q + 1]; ++lr) rinfo[lr] = (static_cast<uint32_t>(q) << 8) | static_cast<uint32_t>(lr - soff[q]);
   __syncthreads();
-  for (int lr = tid; lr < nrows; lr += kConvBlock) {
-    const uint32_t ri = rinfo[lr];
-    const uint4 q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + (ri >> 8)) * MAXN + (ri & 255u)) * WORDS);
-    rbits[lr][0] = q4.x; rbits[lr][1] = q4.y; rbits[lr][2] = q4.z; rbits[lr][3] = q4.w;
+  for (int lr = tid; lr < ntiles * 32; lr += kConvBlock) {
+    uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
+    if (lr < nrows) {
+      const uint32_t ri = rinfo[lr];
+      q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + (ri >> 8)) * MAXN + (ri & 255u)) * WORDS);
+      rbits[lr][0] = q4.x; rbits[lr][1] = q4.y; rbits[lr][2] = q4.z; rbits[lr][3] = q4.w;
+    }
+    if constexpr (SPLIT) {                          // D^-1 = 1 / rowsum(A + I)
+      const int pc = __popc(q4.x) + __popc(q4.y) + __popc(q4.z) + __popc(q4.w);
+      dinvs[lr] = static_cast<float>(1.0 / static_cast<double>(pc + 1));
+    }
   }
   __syncthreads();
 
-  const int ntiles = (nrows + 31) >> 5;             // <= 8
   // my (up to two) row tiles: per lane the row lr = 32 I + r it feeds into the A operand.  (Named scalars, not
   // arrays: indexed by the tile loop they ended up in scratch memory, one scratch load per MFMA step.)
   auto row_ctx = [&](int I) {
@@ -123,21 +178,57 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
       const uint32_t lo = word(w), hi = word(w + 1);
       uint32_t win = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
       if (cx.q < 0) win = 0u;
-      const uint32_t winh = win >> h;                // this lane supplies columns c' = 2 s + h
-      const int cdh = cx.i - p0 - h;                 // the diagonal sits at step s = cdh / 2 when cdh is even and in range
-      const float dval = cx.self ? 2.f * cx.one : cx.one;
-      float bvals[16];
+      if constexpr (SPLIT) {
+        // k = 16 s2 + 8 h + j: this lane supplies 8 consecutive columns per MFMA, two MFMAs per plane
+        const int cd = cx.i - p0;                    // the diagonal's column in this tile (out of range: none)
+        const uint32_t dadd = cx.self ? 0x0080u : 0x3F80u;      // + 1.0 on a bf16 that is 1.0 (-> 2.0 = 0x4000) or 0
+        bf16x8 av[2];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int lc = 32 * J + 2 * s + h;           // the column (= local row of H) this lane supplies
-        bvals[s] = H[lc < nrows ? lc : 0][r];        // (rows past the end may hold anything; their A entries are 0)
+        for (int s2 = 0; s2 < 2; ++s2) {
+          uint4 t = lut[(win >> (16 * s2 + 8 * h)) & 0xFFu];
+          const int dj = cd - (16 * s2 + 8 * h);     // 0..7 when the diagonal falls into this lane's 8 columns
+          const uint32_t add = (dj >= 0 && dj < 8) ? (dadd << (16 * (dj & 1))) : 0u;
+          const int sel = dj >> 1;
+          t.x += sel == 0 ? add : 0u;
+          t.y += sel == 1 ? add : 0u;
+          t.z += sel == 2 ? add : 0u;
+          t.w += sel == 3 ? add : 0u;
+          av[s2] = *reinterpret_cast<bf16x8*>(&t);
+        }
+        bf16x8 bv[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) bv[p][s2] = *reinterpret_cast<const bf16x8*>(&Hp[p][r][32 * J + 16 * s2 + 8 * h]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int p = 2; p >= 0; --p)                 // smallest terms first
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2], bv[p][s2], acc, 0, 0, 0);
+      } else {
+        const uint32_t winh = win >> h;                // this lane supplies columns c' = 2 s + h
+        const int cdh = cx.i - p0 - h;                 // the diagonal sits at step s = cdh / 2 when cdh is even and in range
+        const float dval = cx.self ? 2.f * cx.one : cx.one;
+        float bvals[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int lc = 32 * J + 2 * s + h;           // the column (= local row of H) this lane supplies
+          bvals[s] = H[lc < nrows ? lc : 0][r];        // (rows past the end may hold anything; their A entries are 0)
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          float a = ((winh >> (2 * s)) & 1u) ? cx.one : 0.f;
+          a = cdh == 2 * s ? dval : a;                 // + I (a self loop in A makes it 2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvals[s], acc, 0, 0, 0);
+        }
       }
-      asm volatile("" ::: "memory");
+    }
+    if constexpr (SPLIT) {                           // the row scale D^-1, in the accumulator layout: rows (i & 3) + 8 (i >> 2) + 4 h
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        float a = ((winh >> (2 * s)) & 1u) ? cx.one : 0.f;
-        a = cdh == 2 * s ? dval : a;                 // + I (a self loop in A makes it 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvals[s], acc, 0, 0, 0);
+      for (int g = 0; g < 4; ++g) {
+        const float4 dv = *reinterpret_cast<const float4*>(&dinvs[32 * I + 8 * g + 4 * h]);
+        acc[4 * g + 0] *= dv.x; acc[4 * g + 1] *= dv.y; acc[4 * g + 2] *= dv.z; acc[4 * g + 3] *= dv.w;
       }
     }
 #pragma unroll
@@ -188,8 +279,22 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
     for (int t = 0; t < 2; ++t) {
       const int I = wave + t * (kConvBlock / 64);
       if (I >= ntiles) continue;
+      if constexpr (SPLIT) {
+        // accumulator layout: this lane holds feature r of rows 8 g + 4 h + {0..3}: four bf16 of one plane row = 8 bytes
 #pragma unroll
-      for (int i = 0; i < 16; ++i) H[32 * I + (i & 3) + 8 * (i >> 2) + 4 * h][r] = t == 0 ? hn0[i] : hn1[i];
+        for (int g = 0; g < 4; ++g) {
+          uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) split3(t == 0 ? hn0[4 * g + q] : hn1[4 * g + q], ph[q], pm[q], pl[q]);
+          const int row = 32 * I + 8 * g + 4 * h;
+          *reinterpret_cast<uint2*>(&Hp[0][r][row]) = make_uint2(ph[0] | (ph[1] << 16), ph[2] | (ph[3] << 16));
+          *reinterpret_cast<uint2*>(&Hp[1][r][row]) = make_uint2(pm[0] | (pm[1] << 16), pm[2] | (pm[3] << 16));
+          *reinterpret_cast<uint2*>(&Hp[2][r][row]) = make_uint2(pl[0] | (pl[1] << 16), pl[2] | (pl[3] << 16));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) H[32 * I + (i & 3) + 8 * (i >> 2) + 4 * h][r] = t == 0 ? hn0[i] : hn1[i];
+      }
     }
     __syncthreads();
   }
@@ -203,7 +308,12 @@ LPG_EXPORT int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* f
   LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && ldh >= 32 && ldc >= 96, "seal_conv_stack: bad sizes");
   if (n_windows == 0) return LPG_OK;
   LPG_REQUIRE(node_off && first && adj_bits && h1 && w2 && w3 && w4 && cat && key, "seal_conv_stack: null pointer");
-  hipLaunchKernelGGL(seal_conv_dense_kernel, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0, as_stream(stream),
-                     node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key);
+  const char* env = getenv("LPG_SEAL_CONV_FP32");       // A/B hook: 1 keeps the aggregation on the fp32 matrix cores
+  if (env && atoi(env) != 0)
+    hipLaunchKernelGGL(seal_conv_dense_kernel<false>, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0,
+                       as_stream(stream), node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key);
+  else
+    hipLaunchKernelGGL(seal_conv_dense_kernel<true>, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0,
+                       as_stream(stream), node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key);
   return check_launch("seal_conv_stack");
 }
