@@ -188,13 +188,15 @@ def seal_forward_bench(device, iters=10):
     gen.manual_seed(0)
     emb = torch.randn((620, 100), generator=gen, device=device)       # gensim absent: seeded stand-in
 
+    k1 = hw["conv1d_kernel_1"].reshape(-1, hw["conv1d_kernel_1"].shape[-1])     # [96, 16], fused into the conv stack
+
     def structure():
         return seal.link2subgraph(pos, neg, 620, 0.1, 1, device=device)
 
     def aggregate(batch, tag_map, T):
         h1 = seal.first_layer_h1(batch, tag_map, T, emb, weights[0])               # X W_1 from two row gathers, X never built
-        zc, key = seal.graph_conv_stack(None, None, None, weights, batch=batch, h1=h1)    # dense-block stack, no CSR
-        return seal.head(zc, key, batch.node_off(), hw)[1]       # P(link) per candidate
+        a16, key = seal.graph_conv_stack(None, None, None, weights, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
+        return seal.head(None, key, batch.node_off(), hw, a_all=a16)[1]       # P(link) per candidate
 
     batch, _, T, tag_map, _ = structure()
     aggregate(batch, tag_map, T)
@@ -243,12 +245,13 @@ def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5
           "conv1d_kernel_2": torch.randn(5, 16, 32, device=device) * 0.1,
           "weight_1": torch.randn((k - 4) * 32, 128, device=device) * 0.1, "bias_1": torch.zeros(128, device=device),
           "weight_2": torch.randn(128, 2, device=device), "bias_2": torch.zeros(2, device=device)}
+    k1 = hw["conv1d_kernel_1"].reshape(-1, 16)                                        # fused into the conv stack
 
     def score_fn(p):
         batch = seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=0)
         h1 = seal.first_layer_h1(batch, tag_map, T, emb, gw[0])                    # X W_1 from two row gathers, X never built
-        z, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1)          # dense-block stack, no CSR
-        return seal.head(z, key, batch.node_off(), hw)[1]
+        a16, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
+        return seal.head(None, key, batch.node_off(), hw, a_all=a16)[1]
 
     # No collective in here: a rank that fails must not leave the others hanging at a barrier and take the
     # headline line down with it.  Scores stay sharded (gather=False; the all_gather is 4 B per scored edge);

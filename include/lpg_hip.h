@@ -306,11 +306,15 @@ int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_off, const 
  * cat = [Z_1 | Z_2 | Z_3] [total, >= 96] and key = Z_4[:, 0] [total]; no block CSR, no plan, no intermediate
  * in HBM.  first[w] (int32, n_windows + 1 entries) = the first subgraph whose first row is >= 128 w, i.e.
  * lower_bound(node_off, 128 w) clamped to B, for w = 0 .. ceil(total / 128); a workgroup owns the subgraphs that
- * start in its 128-row window.  w2, w3 are [32,32] with the INPUT index major (TensorFlow's x @ W), w4 is [32]. */
+ * start in its 128-row window.  w2, w3 are [32,32] with the INPUT index major (TensorFlow's x @ W), w4 is [32].
+ * Head fusion: with head_k1 [96,16] (conv1d_kernel_1 of the DGCNN head, SEAL/model/gnn.py:104-110, a per-vertex
+ * linear on the concat) the kernel also writes head_a16 [total,16] = [Z_1|Z_2|Z_3] @ head_k1; cat may then be NULL
+ * (the 96-wide concat is never written).  The aggregation runs on the bf16 matrix cores through an exact three-way
+ * bf16 split of H (0/1/2 adjacency entries are exact in bf16); LPG_SEAL_CONV_FP32=1 keeps the fp32 MFMA form. */
 int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
                             const uint32_t* adj_bits, const float* h1, int64_t ldh, const float* w2,
                             const float* w3, const float* w4, float* cat, int64_t ldc, float* key,
-                            void* stream);
+                            const float* head_k1, float* head_a16, void* stream);
 
 /* ---------------------------------------------------------------- SEAL head
  * SortPooling [SEAL/model/gnn.py:82-91]: per subgraph b, order its n_b vertices by key (= Z_4[:,0])

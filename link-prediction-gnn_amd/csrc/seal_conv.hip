@@ -29,32 +29,11 @@ using namespace lpg;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
-// ---- the aggregation on the BF16 matrix cores, exactly -------------------------------------------------------
-// (A + I) has entries 0 / 1 / 2: exact in bf16.  An fp32 value splits exactly into three bf16 terms (8 + 8 + 8
-// mantissa bits: hi = the top 16 bits, mid = the top 16 bits of v - hi, lo = v - hi - mid).  So
-//   (A + I) H = (A + I) H_hi + (A + I) H_mid + (A + I) H_lo
-// with every product exact and the sums in the MFMA's fp32 accumulator: the same arithmetic class as the fp32
-// matrix-core product, on v_mfma_f32_32x32x16_bf16 -- 6 MFMAs of 32 cycles per 32 x 32 block instead of 16
-// v_mfma_f32_32x32x2_f32 of 64 cycles (the aggregation loop was 0.66 of this kernel's 1.2 ms, serial MFMA chains).
-// D^-1 is a row scale applied to the accumulator before tanh.  H lives in LDS as three TRANSPOSED bf16 planes
-// ([plane][feature][row]: the B operand's 8 consecutive k = 8 consecutive rows of one feature is one 16-byte read);
-// the A operand (8 consecutive bits of the row's adjacency window) comes from a 256-entry byte -> 8 x bf16 table.
-
 constexpr int MAXN = LPG_SEAL_MAXN;   // 128
 constexpr int WORDS = MAXN / 32;
 constexpr int WIN = 128;              // a workgroup owns the subgraphs that start in a 128-row window
 constexpr int RMAX = WIN + MAXN;      // rows it can end up with (<= 255), rounded to tiles of 32
 constexpr int kConvBlock = 256;       // 4 waves, up to two 32-row tiles each (a workgroup has at most 8)
-constexpr int HS = 256 + 8;           // row stride of a transposed bf16 plane (528 B: 16-byte aligned, 4 banks apart)
-
-// exact three-way split of an fp32 value into bf16 terms (truncations; each remainder is exact in fp32)
-__device__ __forceinline__ void split3(float v, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  const uint32_t uh = __float_as_uint(v) & 0xFFFF0000u;
-  const float r1 = v - __uint_as_float(uh);
-  const uint32_t um = __float_as_uint(r1) & 0xFFFF0000u;
-  const float r2 = r1 - __uint_as_float(um);
-  hi = uh >> 16; mid = um >> 16; lo = __float_as_uint(r2) >> 16;
-}
 
 // tanh(v) = 1 - 2 / (exp(2 v) + 1) with the hardware reciprocal (1 ulp): |error| < 3e-7 absolute on an output in
 // [-1, 1], branch-free; saturates cleanly (exp -> inf gives 1, exp -> 0 gives -1).
@@ -67,15 +46,11 @@ struct RowCtx {
   uint32_t b0, b1, b2, b3;   // the row's adjacency bits
 };
 
-template <bool SPLIT>          // SPLIT: aggregation on the bf16 matrix cores (exact three-way split), else fp32 MFMA
 __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
     const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
     const float* __restrict__ h1, int64_t ldh, const float* __restrict__ w2, const float* __restrict__ w3,
     const float* __restrict__ w4, float* __restrict__ cat, int64_t ldc, float* __restrict__ key) {
-  __shared__ __attribute__((aligned(16))) float H[SPLIT ? 1 : RMAX][32];          // fp32 path: the current layer's H rows
-  __shared__ __attribute__((aligned(16))) uint16_t Hp[SPLIT ? 3 : 1][SPLIT ? 32 : 1][SPLIT ? HS : 8];   // bf16 planes, transposed
-  __shared__ __attribute__((aligned(16))) uint4 lut[SPLIT ? 256 : 1];            // byte -> 8 x bf16 {0, 1}
-  __shared__ __attribute__((aligned(16))) float dinvs[SPLIT ? RMAX : 4];         // D^-1 per local row
+  __shared__ float H[RMAX][32];                     // 32 KB: the current layer's H rows of the owned subgraphs
   __shared__ uint32_t rinfo[RMAX];                  // per local row: (local subgraph index << 8) | vertex index
   __shared__ uint32_t rbits[RMAX][WORDS];           // its adjacency row
   __shared__ int soff[WIN + 2];                     // local row offset of each owned subgraph
@@ -87,7 +62,6 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
   const int nsub = bl - bf;                         // <= 128: every owned subgraph starts in the window
   const int64_t r_lo = node_off[bf];
   const int nrows = static_cast<int>(node_off[bl] - r_lo);
-  const int ntiles = (nrows + 31) >> 5;             // <= 8
 
   // the loads that depend on nothing but the window come first: they fly during the index work below
   // W_{l+1} in the B-operand layout: lane (n = r, h) holds W[k = 2 s + h][n] for s = 0..15
@@ -98,47 +72,21 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
     Wb3[s] = w3[(2 * s + h) * 32 + r];
     Wb4[s] = r == 0 ? w4[2 * s + h] : 0.f;          // 32 -> 1 as a 32 x 32 product whose column 0 is the result
   }
-  if constexpr (SPLIT) {
-    // H_1 -> three transposed bf16 planes; rows [nrows, 32 ntiles) are zero (their A entries are zero, but 0 x NaN is not)
-    for (int idx = tid; idx < ntiles * 32 * 32; idx += kConvBlock) {
-      const int row = idx >> 5, c = idx & 31;
-      const float v = row < nrows ? h1[(r_lo + row) * ldh + c] : 0.f;
-      uint32_t a0, a1, a2;
-      split3(v, a0, a1, a2);
-      Hp[0][c][row] = static_cast<uint16_t>(a0);
-      Hp[1][c][row] = static_cast<uint16_t>(a1);
-      Hp[2][c][row] = static_cast<uint16_t>(a2);
-    }
-    {                                               // byte -> 8 bf16 (bit j set -> 1.0 = 0x3F80 in element j)
-      uint32_t d[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        d[q] = (((tid >> (2 * q)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * q + 1)) & 1) ? 0x3F800000u : 0u);
-      lut[tid] = make_uint4(d[0], d[1], d[2], d[3]);
-    }
-  } else {
-    for (int idx = tid; idx < nrows * 32; idx += kConvBlock) H[idx >> 5][idx & 31] = h1[(r_lo + (idx >> 5)) * ldh + (idx & 31)];
-  }
+  for (int idx = tid; idx < nrows * 32; idx += kConvBlock) H[idx >> 5][idx & 31] = h1[(r_lo + (idx >> 5)) * ldh + (idx & 31)];
   // ---- per-subgraph offsets, per-row (subgraph, vertex) and adjacency rows
   for (int q = tid; q <= nsub; q += kConvBlock) soff[q] = static_cast<int>(node_off[bf + q] - r_lo);
   __syncthreads();
   for (int q = tid; q < nsub; q += kConvBlock)
     for (int lr = soff[q]; lr < soff[q + 1]; ++lr) rinfo[lr] = (static_cast<uint32_t>(q) << 8) | static_cast<uint32_t>(lr - soff[q]);
   __syncthreads();
-  for (int lr = tid; lr < ntiles * 32; lr += kConvBlock) {
-    uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
-    if (lr < nrows) {
-      const uint32_t ri = rinfo[lr];
-      q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + (ri >> 8)) * MAXN + (ri & 255u)) * WORDS);
-      rbits[lr][0] = q4.x; rbits[lr][1] = q4.y; rbits[lr][2] = q4.z; rbits[lr][3] = q4.w;
-    }
-    if constexpr (SPLIT) {                          // D^-1 = 1 / rowsum(A + I)
-      const int pc = __popc(q4.x) + __popc(q4.y) + __popc(q4.z) + __popc(q4.w);
-      dinvs[lr] = static_cast<float>(1.0 / static_cast<double>(pc + 1));
-    }
+  for (int lr = tid; lr < nrows; lr += kConvBlock) {
+    const uint32_t ri = rinfo[lr];
+    const uint4 q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + (ri >> 8)) * MAXN + (ri & 255u)) * WORDS);
+    rbits[lr][0] = q4.x; rbits[lr][1] = q4.y; rbits[lr][2] = q4.z; rbits[lr][3] = q4.w;
   }
   __syncthreads();
 
+  const int ntiles = (nrows + 31) >> 5;             // <= 8
   // my (up to two) row tiles: per lane the row lr = 32 I + r it feeds into the A operand.  (Named scalars, not
   // arrays: indexed by the tile loop they ended up in scratch memory, one scratch load per MFMA step.)
   auto row_ctx = [&](int I) {
@@ -178,57 +126,21 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
       const uint32_t lo = word(w), hi = word(w + 1);
       uint32_t win = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
       if (cx.q < 0) win = 0u;
-      if constexpr (SPLIT) {
-        // k = 16 s2 + 8 h + j: this lane supplies 8 consecutive columns per MFMA, two MFMAs per plane
-        const int cd = cx.i - p0;                    // the diagonal's column in this tile (out of range: none)
-        const uint32_t dadd = cx.self ? 0x0080u : 0x3F80u;      // + 1.0 on a bf16 that is 1.0 (-> 2.0 = 0x4000) or 0
-        bf16x8 av[2];
+      const uint32_t winh = win >> h;                // this lane supplies columns c' = 2 s + h
+      const int cdh = cx.i - p0 - h;                 // the diagonal sits at step s = cdh / 2 when cdh is even and in range
+      const float dval = cx.self ? 2.f * cx.one : cx.one;
+      float bvals[16];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          uint4 t = lut[(win >> (16 * s2 + 8 * h)) & 0xFFu];
-          const int dj = cd - (16 * s2 + 8 * h);     // 0..7 when the diagonal falls into this lane's 8 columns
-          const uint32_t add = (dj >= 0 && dj < 8) ? (dadd << (16 * (dj & 1))) : 0u;
-          const int sel = dj >> 1;
-          t.x += sel == 0 ? add : 0u;
-          t.y += sel == 1 ? add : 0u;
-          t.z += sel == 2 ? add : 0u;
-          t.w += sel == 3 ? add : 0u;
-          av[s2] = *reinterpret_cast<bf16x8*>(&t);
-        }
-        bf16x8 bv[3][2];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) bv[p][s2] = *reinterpret_cast<const bf16x8*>(&Hp[p][r][32 * J + 16 * s2 + 8 * h]);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int p = 2; p >= 0; --p)                 // smallest terms first
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2], bv[p][s2], acc, 0, 0, 0);
-      } else {
-        const uint32_t winh = win >> h;                // this lane supplies columns c' = 2 s + h
-        const int cdh = cx.i - p0 - h;                 // the diagonal sits at step s = cdh / 2 when cdh is even and in range
-        const float dval = cx.self ? 2.f * cx.one : cx.one;
-        float bvals[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const int lc = 32 * J + 2 * s + h;           // the column (= local row of H) this lane supplies
-          bvals[s] = H[lc < nrows ? lc : 0][r];        // (rows past the end may hold anything; their A entries are 0)
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          float a = ((winh >> (2 * s)) & 1u) ? cx.one : 0.f;
-          a = cdh == 2 * s ? dval : a;                 // + I (a self loop in A makes it 2)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvals[s], acc, 0, 0, 0);
-        }
+      for (int s = 0; s < 16; ++s) {
+        const int lc = 32 * J + 2 * s + h;           // the column (= local row of H) this lane supplies
+        bvals[s] = H[lc < nrows ? lc : 0][r];        // (rows past the end may hold anything; their A entries are 0)
       }
-    }
-    if constexpr (SPLIT) {                           // the row scale D^-1, in the accumulator layout: rows (i & 3) + 8 (i >> 2) + 4 h
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 dv = *reinterpret_cast<const float4*>(&dinvs[32 * I + 8 * g + 4 * h]);
-        acc[4 * g + 0] *= dv.x; acc[4 * g + 1] *= dv.y; acc[4 * g + 2] *= dv.z; acc[4 * g + 3] *= dv.w;
+      for (int s = 0; s < 16; ++s) {
+        float a = ((winh >> (2 * s)) & 1u) ? cx.one : 0.f;
+        a = cdh == 2 * s ? dval : a;                 // + I (a self loop in A makes it 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvals[s], acc, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -279,21 +191,268 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
     for (int t = 0; t < 2; ++t) {
       const int I = wave + t * (kConvBlock / 64);
       if (I >= ntiles) continue;
-      if constexpr (SPLIT) {
-        // accumulator layout: this lane holds feature r of rows 8 g + 4 h + {0..3}: four bf16 of one plane row = 8 bytes
+#pragma unroll
+      for (int i = 0; i < 16; ++i) H[32 * I + (i & 3) + 8 * (i >> 2) + 4 * h][r] = t == 0 ? hn0[i] : hn1[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================================================================
+// The default kernel: the same four layers, TRANSPOSED and on the bf16 matrix cores -- exactly.
+//
+// (1) Exact bf16 aggregation.  (A + I) has entries 0 / 1 / 2: exact in bf16.  An fp32 value splits exactly into three
+//     bf16 terms (8 + 8 + 8 mantissa bits: hi = the top 16 bits, mid = the top 16 bits of v - hi, lo = v - hi - mid),
+//     so (A + I) H = (A + I) H_hi + (A + I) H_mid + (A + I) H_lo with every product exact and the sums in the MFMA's
+//     fp32 accumulator: the arithmetic class of the fp32 matrix-core product, on v_mfma_f32_32x32x16_bf16 -- 6 MFMAs
+//     of 32 cycles per 32 x 32 block instead of 16 v_mfma_f32_32x32x2_f32 of 64 cycles (the aggregation loop was
+//     0.66 of the fp32 kernel's 1.2 ms: serial MFMA chains).  D^-1 is a scale applied before tanh.
+// (2) Transposed products.  Z^T = H^T (A + I)^T D^-1: the A operand is a fragment of H^T (feature r, 8 consecutive
+//     vertices: one 16-byte read of a TRANSPOSED bf16 plane [plane][feature][row]), the B operand 8 consecutive bits
+//     of the lane's own adjacency row through a 256-entry byte -> 8 x bf16 table (A is symmetric).  The result lands
+//     with lane = vertex, registers = features -- which is already the B-operand layout of the next product
+//     H'^T = W^T Z^T (the contraction index may be visited in any order as long as both operands agree, so W is
+//     staged in LDS in the accumulator's feature order).  No transposition through LDS, no per-row scale lookup
+//     (D^-1 is the lane's own), and the concat rows leave as 16-byte pieces.
+// (3) Head fusion.  conv1d #1 of the DGCNN head (SEAL/model/gnn.py:104-110) is a per-vertex linear on
+//     [Z_1 | Z_2 | Z_3]; with head_k1 the kernel accumulates a16^T = sum_l k1_l^T Z_l^T next to H'^T and the 96-wide
+//     concat is neither written nor read back (562 MB each way per 100 K candidates).
+constexpr int HS = 256 + 8;           // row stride of a transposed bf16 plane (528 B: 16-byte aligned, 4 banks apart)
+
+// exact three-way split of an fp32 value into bf16 terms (truncations; each remainder is exact in fp32)
+__device__ __forceinline__ void split3(float v, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const uint32_t uh = __float_as_uint(v) & 0xFFFF0000u;
+  const float r1 = v - __uint_as_float(uh);
+  const uint32_t um = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(um);
+  hi = uh >> 16; mid = um >> 16; lo = __float_as_uint(r2) >> 16;
+}
+
+// feature index of accumulator register i in lane half h (32 x 32 accumulator: row = (i & 3) + 8 (i >> 2) + 4 h)
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+struct RowCtxT {
+  int i, start;        // vertex index inside its subgraph (-100000: no row), the subgraph's first local row
+  float one;           // D^-1 of the row (0: no row)
+  uint32_t dadd;       // what "+ 1.0" is on the diagonal's bf16: 0x0080 when it already holds 1.0 (self loop), else 0x3F80
+  uint32_t b0, b1, b2, b3;   // the row's adjacency bits
+  int j_lo, j_hi;      // column tiles the tile's subgraphs overlap
+};
+
+__global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
+    const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
+    const float* __restrict__ h1, int64_t ldh, const float* __restrict__ w2, const float* __restrict__ w3,
+    const float* __restrict__ w4, float* __restrict__ cat, int64_t ldc, float* __restrict__ key,
+    const float* __restrict__ k1, float* __restrict__ a16) {
+  __shared__ __attribute__((aligned(16))) uint16_t Hp[3][32][HS];      // H^T as three bf16 planes
+  __shared__ __attribute__((aligned(16))) uint4 lut[256];             // byte -> 8 x bf16 {0, 1}
+  __shared__ __attribute__((aligned(16))) float Wl[2][4][64][4];      // W_2, W_3 as A operands: [layer][i >> 2][lane][i & 3]
+  __shared__ __attribute__((aligned(16))) float Kl[3][4][2][16][4];   // k1 slices as A operands: [layer][i >> 2][h][c][i & 3]
+  __shared__ uint32_t rinfo[RMAX];                  // per local row: (local subgraph index << 8) | vertex index
+  __shared__ int soff[WIN + 2];                     // local row offset of each owned subgraph
+  __shared__ __attribute__((aligned(16))) float zt[kConvBlock / 64][16][36];   // wave-private half tile: concat rows leave as whole lines
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bf = first[blockIdx.x], bl = first[blockIdx.x + 1];
+  if (bl <= bf) return;                             // a window inside one big subgraph owns nothing
+  const int nsub = bl - bf;                         // <= 128: every owned subgraph starts in the window
+  const int64_t r_lo = node_off[bf];
+  const int nrows = static_cast<int>(node_off[bl] - r_lo);
+  const int ntiles = (nrows + 31) >> 5;             // <= 8
+
+  // ---- everything that depends on nothing but the window: H_1 planes, the bit table, the weight operands
+  // rows [nrows, 32 ntiles) are zero (their adjacency entries are zero, but 0 x NaN is not)
+  for (int idx = tid; idx < ntiles * 32 * 32; idx += kConvBlock) {
+    const int row = idx >> 5, c = idx & 31;
+    const float v = row < nrows ? h1[(r_lo + row) * ldh + c] : 0.f;
+    uint32_t a0, a1, a2;
+    split3(v, a0, a1, a2);
+    Hp[0][c][row] = static_cast<uint16_t>(a0);
+    Hp[1][c][row] = static_cast<uint16_t>(a1);
+    Hp[2][c][row] = static_cast<uint16_t>(a2);
+  }
+  {                                                 // byte -> 8 bf16 (bit j set -> 1.0 = 0x3F80 in element j)
+    uint32_t d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      d[q] = (((tid >> (2 * q)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * q + 1)) & 1) ? 0x3F800000u : 0u);
+    lut[tid] = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+  for (int idx = tid; idx < 2 * 64 * 16; idx += kConvBlock) {          // W[f][o] -> [layer][i >> 2][lane = (o, h)][i & 3]
+    const int l = idx >> 10, ln = (idx >> 4) & 63, i = idx & 15;
+    Wl[l][i >> 2][ln][i & 3] = (l == 0 ? w2 : w3)[acc_row(i, ln >> 5) * 32 + (ln & 31)];
+  }
+  if (k1)
+    for (int idx = tid; idx < 3 * 2 * 16 * 16; idx += kConvBlock) {   // k1[32 l + f][c] -> [layer][i >> 2][h][c][i & 3]
+      const int l = idx >> 9, hh = (idx >> 8) & 1, c = (idx >> 4) & 15, i = idx & 15;
+      Kl[l][i >> 2][hh][c][i & 3] = k1[(l * 32 + acc_row(i, hh)) * 16 + c];
+    }
+  // ---- per-subgraph offsets, per-row (subgraph, vertex)
+  for (int q = tid; q <= nsub; q += kConvBlock) soff[q] = static_cast<int>(node_off[bf + q] - r_lo);
+  __syncthreads();
+  for (int q = tid; q < nsub; q += kConvBlock)
+    for (int lr = soff[q]; lr < soff[q + 1]; ++lr) rinfo[lr] = (static_cast<uint32_t>(q) << 8) | static_cast<uint32_t>(lr - soff[q]);
+  __syncthreads();
+
+  // my (up to two) row tiles: the lane's vertex is local row 32 I + r.  (Named scalars, not arrays: indexed by the
+  // tile loop they would live in scratch memory.)
+  auto row_ctx = [&](int I) {
+    RowCtxT c{-100000, 0, 0.f, 0x3F80u, 0u, 0u, 0u, 0u, 0, -1};
+    if (I >= ntiles) return c;
+    const int lr0 = 32 * I, lr1 = min(32 * I + 31, nrows - 1);
+    c.j_lo = soff[rinfo[lr0] >> 8] >> 5;
+    c.j_hi = (soff[(rinfo[lr1] >> 8) + 1] - 1) >> 5;
+    const int lr = 32 * I + r;
+    if (lr < nrows) {
+      const uint32_t ri = rinfo[lr];
+      const int q = static_cast<int>(ri >> 8);
+      c.i = static_cast<int>(ri & 255u);
+      c.start = soff[q];
+      const uint4 q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + q) * MAXN + c.i) * WORDS);
+      c.b0 = q4.x; c.b1 = q4.y; c.b2 = q4.z; c.b3 = q4.w;
+      const int pc = __popc(c.b0) + __popc(c.b1) + __popc(c.b2) + __popc(c.b3);
+      c.one = static_cast<float>(1.0 / static_cast<double>(pc + 1));             // D^-1 = 1 / rowsum(A + I)
+      const uint32_t wi = c.i < 32 ? c.b0 : (c.i < 64 ? c.b1 : (c.i < 96 ? c.b2 : c.b3));
+      c.dadd = ((wi >> (c.i & 31)) & 1u) ? 0x0080u : 0x3F80u;
+    }
+    return c;
+  };
+  const RowCtxT ctx0 = row_ctx(wave), ctx1 = row_ctx(wave + kConvBlock / 64);
+
+  // Z^T of row tile I: tanh(D^-1 sum_J H_J^T (A + I)_{IJ}^T); lane = vertex, register i = feature acc_row(i, h)
+  auto aggregate = [&](const RowCtxT& cx) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int J = cx.j_lo; J <= cx.j_hi; ++J) {
+      // The columns of tile J that belong to my row's subgraph are a contiguous run of its vertices: column c' is
+      // vertex p0 + c'.  So the 32 entries of (A + I)[my row][tile J] are a 32-bit WINDOW of my 128-bit adjacency
+      // row starting at bit p0 (zero outside the subgraph), plus the diagonal: one funnel shift per block.
+      const int p0 = 32 * J - cx.start;
+      const int w = p0 >> 5, sh = p0 & 31;           // arithmetic shift: p0 may be negative
+      auto word = [&](int k) { return k == 0 ? cx.b0 : (k == 1 ? cx.b1 : (k == 2 ? cx.b2 : (k == 3 ? cx.b3 : 0u))); };
+      const uint32_t lo = word(w), hi = word(w + 1);
+      const uint32_t win = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;       // (no row: the bits are all zero)
+      const int cd = cx.i - p0;                      // the diagonal's column in this tile (out of range: none)
+      bf16x8 av[2];                                  // k = 16 s2 + 8 h + j: 8 consecutive columns per MFMA
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 t = lut[(win >> (16 * s2 + 8 * h)) & 0xFFu];
+        const int dj = cd - (16 * s2 + 8 * h);       // 0..7 when the diagonal falls into this lane's 8 columns
+        const uint32_t add = (dj >= 0 && dj < 8) ? (cx.dadd << (16 * (dj & 1))) : 0u;
+        const int sel = dj >> 1;
+        t.x += sel == 0 ? add : 0u;
+        t.y += sel == 1 ? add : 0u;
+        t.z += sel == 2 ? add : 0u;
+        t.w += sel == 3 ? add : 0u;
+        av[s2] = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int p = 2; p >= 0; --p)                   // smallest terms first
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 hv = *reinterpret_cast<const bf16x8*>(&Hp[p][r][32 * J + 16 * s2 + 8 * h]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hv, av[s2], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = tanh_fast_div(acc[i] * cx.one);
+    return acc;
+  };
+
+  f32x16 aa0, aa1;                                   // a16^T tiles (head fusion)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) aa0[i] = aa1[i] = 0.f;
+#pragma unroll 1
+  for (int layer = 1; layer <= 4; ++layer) {
+    f32x16 hn0, hn1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int I = wave + t * (kConvBlock / 64);
+      if (I >= ntiles) continue;                     // wave-uniform
+      const f32x16 z = aggregate(t == 0 ? ctx0 : ctx1);
+      const int lr = 32 * I + r;
+      if (layer == 4) {
+        if (h == 0 && lr < nrows) key[r_lo + lr] = z[0];            // feature 0
+        continue;
+      }
+      if (cat) {
+        // lane = vertex here; written as they are the rows would leave in 32-byte pieces of 32 different rows per
+        // instruction (2.3 ms instead of 0.9 for the kernel).  Half a tile at a time goes through a wave-private
+        // LDS slice and leaves with 8 lanes per row: whole 128-byte lines.
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if ((r >> 4) == half) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)                // features 8 g + 4 h + {0..3}
+              *reinterpret_cast<float4*>(&zt[wave][r & 15][8 * g + 4 * h]) = make_float4(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the slice is wave-private
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int row = (lane >> 3) + 8 * k, quad = lane & 7;
+            const float4 v = *reinterpret_cast<const float4*>(&zt[wave][row][4 * quad]);
+            const int lrr = 32 * I + 16 * half + row;
+            if (lrr < nrows) *reinterpret_cast<float4*>(cat + (r_lo + lrr) * ldc + (layer - 1) * 32 + 4 * quad) = v;
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_wave_barrier();             // the slice is rewritten by the next half
+        }
+      }
+      // H'^T = W^T Z^T: step i contracts feature acc_row(i, h); A operand = W[feature][o = r] from LDS, B = z[i]
+      f32x16 hn;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hn[i] = 0.f;
+      if (layer < 3) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          uint32_t ph[4], pm[4], pl[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) split3(t == 0 ? hn0[4 * g + q] : hn1[4 * g + q], ph[q], pm[q], pl[q]);
-          const int row = 32 * I + 8 * g + 4 * h;
-          *reinterpret_cast<uint2*>(&Hp[0][r][row]) = make_uint2(ph[0] | (ph[1] << 16), ph[2] | (ph[3] << 16));
-          *reinterpret_cast<uint2*>(&Hp[1][r][row]) = make_uint2(pm[0] | (pm[1] << 16), pm[2] | (pm[3] << 16));
-          *reinterpret_cast<uint2*>(&Hp[2][r][row]) = make_uint2(pl[0] | (pl[1] << 16), pl[2] | (pl[3] << 16));
+          const float4 wv = *reinterpret_cast<const float4*>(&Wl[layer - 1][g][lane][0]);
+          hn = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, z[4 * g + 0], hn, 0, 0, 0);
+          hn = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, z[4 * g + 1], hn, 0, 0, 0);
+          hn = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, z[4 * g + 2], hn, 0, 0, 0);
+          hn = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, z[4 * g + 3], hn, 0, 0, 0);
         }
-      } else {
+      } else {                                       // 32 -> 1: only output row o = 0 is non-zero
 #pragma unroll
-        for (int i = 0; i < 16; ++i) H[32 * I + (i & 3) + 8 * (i >> 2) + 4 * h][r] = t == 0 ? hn0[i] : hn1[i];
+        for (int i = 0; i < 16; ++i) {
+          const float wv = r == 0 ? w4[acc_row(i, h)] : 0.f;
+          hn = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, z[i], hn, 0, 0, 0);
+        }
+      }
+      if (t == 0) hn0 = hn; else hn1 = hn;
+      if (k1) {                                      // wave-uniform
+        f32x16 aa = t == 0 ? aa0 : aa1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 kv = *reinterpret_cast<const float4*>(&Kl[layer - 1][g][h][r & 15][0]);
+          if (r >= 16) kv = make_float4(0.f, 0.f, 0.f, 0.f);
+          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, z[4 * g + 0], aa, 0, 0, 0);
+          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, z[4 * g + 1], aa, 0, 0, 0);
+          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, z[4 * g + 2], aa, 0, 0, 0);
+          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, z[4 * g + 3], aa, 0, 0, 0);
+        }
+        if (t == 0) aa0 = aa; else aa1 = aa;
+        if (layer == 3 && lr < nrows) {              // outputs c = acc_row(i, h) < 16  <=>  i < 8
+          *reinterpret_cast<float4*>(a16 + (r_lo + lr) * 16 + 4 * h) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+          *reinterpret_cast<float4*>(a16 + (r_lo + lr) * 16 + 8 + 4 * h) = make_float4(aa[4], aa[5], aa[6], aa[7]);
+        }
+      }
+    }
+    if (layer == 4) break;
+    __syncthreads();                                 // every aggregation of this layer has read H
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int I = wave + t * (kConvBlock / 64);
+      if (I >= ntiles) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                 // lane = vertex 32 I + r, register i = feature acc_row(i, h)
+        uint32_t ph, pm, pl;
+        split3(t == 0 ? hn0[i] : hn1[i], ph, pm, pl);
+        const int f = acc_row(i, h);
+        Hp[0][f][32 * I + r] = static_cast<uint16_t>(ph);
+        Hp[1][f][32 * I + r] = static_cast<uint16_t>(pm);
+        Hp[2][f][32 * I + r] = static_cast<uint16_t>(pl);
       }
     }
     __syncthreads();
@@ -304,16 +463,22 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_dense_kernel(
 LPG_EXPORT int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
                                        const uint32_t* adj_bits, const float* h1, int64_t ldh, const float* w2,
                                        const float* w3, const float* w4, float* cat, int64_t ldc, float* key,
-                                       void* stream) {
-  LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && ldh >= 32 && ldc >= 96, "seal_conv_stack: bad sizes");
+                                       const float* head_k1, float* head_a16, void* stream) {
+  LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && ldh >= 32 && (!cat || ldc >= 96), "seal_conv_stack: bad sizes");
   if (n_windows == 0) return LPG_OK;
-  LPG_REQUIRE(node_off && first && adj_bits && h1 && w2 && w3 && w4 && cat && key, "seal_conv_stack: null pointer");
-  const char* env = getenv("LPG_SEAL_CONV_FP32");       // A/B hook: 1 keeps the aggregation on the fp32 matrix cores
-  if (env && atoi(env) != 0)
-    hipLaunchKernelGGL(seal_conv_dense_kernel<false>, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0,
+  LPG_REQUIRE(node_off && first && adj_bits && h1 && w2 && w3 && w4 && key, "seal_conv_stack: null pointer");
+  LPG_REQUIRE((cat || head_k1) && (!head_k1 == !head_a16), "seal_conv_stack: needs cat, or head_k1 together with head_a16");
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  const char* env = getenv("LPG_SEAL_CONV_FP32");       // A/B hook: 1 = the first formulation (fp32 MFMA, no head fusion)
+  if (env && atoi(env) != 0) {
+    LPG_REQUIRE(cat && !head_k1, "seal_conv_stack: the fp32 A/B kernel writes cat only");
+    hipLaunchKernelGGL(seal_conv_dense_kernel, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0,
                        as_stream(stream), node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key);
-  else
-    hipLaunchKernelGGL(seal_conv_dense_kernel<true>, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0,
-                       as_stream(stream), node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key);
+    return check_launch("seal_conv_stack (fp32)");
+  }
+  LPG_REQUIRE((!cat || (al16(cat) && ldc % 4 == 0)) && (!head_a16 || al16(head_a16)),
+              "seal_conv_stack: cat / head_a16 must be 16-byte aligned (ldc a multiple of 4)");
+  hipLaunchKernelGGL(seal_conv_t_kernel, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0, as_stream(stream),
+                     node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16);
   return check_launch("seal_conv_stack");
 }

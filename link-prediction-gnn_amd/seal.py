@@ -317,9 +317,11 @@ def _dense_ok(weights, dtype=torch.float32):
             and os.environ.get("LPG_SEAL_DENSE", "1") != "0")
 
 
-def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None):
+def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None, head_k1=None):
     """SEAL/model/gnn.py:46-63: Z_l = tanh(D^-1 (A~ (Z_{l-1} W_l))), l = 1..4.
     Returns (concat(Z1, Z2, Z3) [total, 96], Z4[:, 0] -- the SortPooling key, :82).
+    head_k1 ([96, 16], dense path only): conv1d #1 of the head is fused in and the first return value is
+    concat(Z1, Z2, Z3) @ head_k1 [total, 16] instead -- the 96-wide concat is never written (head(a_all=...)).
     With `batch` (the SubgraphBatch) and the reference's fp32 architecture (widths 32/32/32/1) layers 1..4 run as
     dense 32 x 32 block products on the matrix cores straight from the bit adjacency
     (lpg_seal_conv_stack_f32; g / d_inv may then be None, and with h1 = first_layer_h1(...) so may x);
@@ -334,14 +336,21 @@ def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None):
         n_win = -(-total // 128)
         first = torch.searchsorted(off, torch.arange(n_win + 1, device=h1.device, dtype=torch.int64) * 128)
         first = first.clamp_(max=batch.B).to(torch.int32)
-        cat = torch.empty((total, 96), dtype=torch.float32, device=h1.device)
+        fuse = head_k1 is not None
+        cat = None if fuse else torch.empty((total, 96), dtype=torch.float32, device=h1.device)
+        a16 = torch.empty((total, 16), dtype=torch.float32, device=h1.device) if fuse else None
+        k1 = _ops._c(head_k1, torch.float32) if fuse else None
+        if fuse and tuple(k1.shape) != (96, 16):
+            raise ValueError("graph_conv_stack: head_k1 must be [96, 16]")
         key = torch.empty(total, dtype=torch.float32, device=h1.device)
         w2, w3, w4 = (_ops._c(w, torch.float32) for w in weights[1:])
         P = _ops._ptr
         _lib.check(lib.lpg_seal_conv_stack_f32(P(off), P(first), n_win, P(batch.adj_bits), P(h1), h1.stride(0), P(w2),
-                                               P(w3), P(w4), P(cat), cat.stride(0), P(key), _ops._stream()),
+                                               P(w3), P(w4), P(cat), 96, P(key), P(k1), P(a16), _ops._stream()),
                    "seal_conv_stack")
-        return cat, key
+        return (a16 if fuse else cat), key
+    if head_k1 is not None:
+        raise ValueError("graph_conv_stack: head_k1 is fused only on the dense path (batch=, fp32 widths 32/32/32/1)")
     if g is None:
         raise ValueError("graph_conv_stack: the generic path needs the block CSR (gnn_inputs(build_csr=True))")
     widths = [w.shape[1] for w in weights]
@@ -369,13 +378,15 @@ def sortpool(z, key, node_off, k):
     return out
 
 
-def head(z, key, node_off, hw):
+def head(z, key, node_off, hw, a_all=None):
     """The DGCNN head of SEAL/model/gnn.py:82-137, batched over all subgraphs:
     SortPooling -> conv1d(96->16, stride 96) -> conv1d(width 5, 16->32) -> dense 128 relu -> dense 2
     -> softmax.  Every stage is one launch on the whole batch; the two 1-D convolutions are matmuls
     over (overlapping) row windows of the previous buffer, so nothing is gathered or copied.
     hw: dict with conv1d_kernel_1 [96,1,16], conv1d_kernel_2 [5,16,32], weight_1 [448,128], bias_1,
-    weight_2 [128,2], bias_2 (the shipped checkpoint's tensors).  Returns (pre_y [B,2], score [B])."""
+    weight_2 [128,2], bias_2 (the shipped checkpoint's tensors).  Returns (pre_y [B,2], score [B]).
+    a_all: z @ conv1d_kernel_1 [total, 16] when the conv stack already produced it (graph_conv_stack(head_k1=));
+    z may then be None."""
     lib = _lib.load()
     k1 = hw["conv1d_kernel_1"].reshape(-1, hw["conv1d_kernel_1"].shape[-1])          # [96, 16]
     k2 = hw["conv1d_kernel_2"].reshape(-1, hw["conv1d_kernel_2"].shape[-1])          # [80, 32] (dt-major)
@@ -385,14 +396,16 @@ def head(z, key, node_off, hw):
     # conv1d #1 is a per-vertex linear (stride = filter width = one 96-wide row) with no activation, and SortPooling
     # only gathers rows (zero rows stay zero): conv1d(sortpool(z)) == sortpool(z @ k1) value for value.  Multiplying
     # first moves 16-float rows through the pooling instead of 96-float ones (1.25 GB less traffic per 100 K subgraphs).
-    a = sortpool(_ops.linear(z, k1, w_is_km=True), key, node_off, k).view(B * k, -1)      # [B*k, 16]
+    if a_all is None:
+        a_all = _ops.linear(z, k1, w_is_km=True)
+    a = sortpool(a_all, key, node_off, k).view(B * k, -1)                                # [B*k, 16]
     # rows t >= k - fw + 1 of a subgraph's block are windows that run into the next subgraph; the dense layer below
     # reads only the first (k - fw + 1) * c2 values of each block, so they (and the unwritten tail) are never used
-    c = torch.empty((B * k, c2), dtype=torch.float32, device=z.device)
+    c = torch.empty((B * k, c2), dtype=torch.float32, device=a.device)
     _ops.linear(a, k2, w_is_km=True, n=B * k - (fw - 1), ldx=c1, out=c[: B * k - (fw - 1)])   # windows t..t+4
     dense = _ops.linear(c, hw["weight_1"], hw["bias_1"], w_is_km=True, act="relu", n=B, ldx=k * c2)
     pre_y = _ops.linear(dense, hw["weight_2"], hw["bias_2"], w_is_km=True)
-    score = torch.empty(B, dtype=torch.float32, device=z.device)
+    score = torch.empty(B, dtype=torch.float32, device=a.device)
     _lib.check(lib.lpg_softmax2_pos_score_f32(_ops._ptr(pre_y), B, _ops._ptr(score), _ops._stream()), "softmax2")
     return pre_y, score
 
@@ -402,9 +415,14 @@ def score_links(positive, negative, nodes_size, emb, weights, head_weights, test
     convolutions (a9) and the head.  Returns (scores [B], labels [B,1], batch)."""
     batch, labels, T, tag_map, _ = link2subgraph(positive, negative, nodes_size, test_ratio, hop, device=device)
     if _dense_ok(weights) and emb is not None:          # X is never built: H_1 from two row gathers, then the dense stack
-        z, key = graph_conv_stack(None, None, None, weights, batch=batch, h1=first_layer_h1(batch, tag_map, T, emb, weights[0]))
-    else:
-        g, d_inv, x = gnn_inputs(batch, tag_map, T, emb)
-        z, key = graph_conv_stack(g, d_inv, x, weights, batch=batch)
+        k1 = head_weights["conv1d_kernel_1"]
+        k1 = k1.reshape(-1, k1.shape[-1])
+        fuse = tuple(k1.shape) == (96, 16) and os.environ.get("LPG_SEAL_CONV_FP32", "0") == "0"
+        h1 = first_layer_h1(batch, tag_map, T, emb, weights[0])
+        z, key = graph_conv_stack(None, None, None, weights, batch=batch, h1=h1, head_k1=k1 if fuse else None)
+        _, score = head(None if fuse else z, key, batch.node_off(), head_weights, a_all=z if fuse else None)
+        return score, labels, batch
+    g, d_inv, x = gnn_inputs(batch, tag_map, T, emb)
+    z, key = graph_conv_stack(g, d_inv, x, weights, batch=batch)
     _, score = head(z, key, batch.node_off(), head_weights)
     return score, labels, batch

@@ -34,6 +34,11 @@ if not GENERIC:
     t_h1, h1 = T(lambda: seal.first_layer_h1(batch, tag_map, Tn, emb, gw[0]))
     t_conv2, _ = T(lambda: seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1))
     print(f"table path: first_layer_h1 {t_h1:.3f} + dense stack {t_conv2:.3f} ms (replaces gnn_inputs + conv_stack)")
+    if os.environ.get("LPG_SEAL_CONV_FP32", "0") == "0":
+        k1 = hw["conv1d_kernel_1"].reshape(-1, 16)
+        t_conv3, (a16, key3) = T(lambda: seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1))
+        t_head3, _ = T(lambda: seal.head(None, key3, batch.node_off(), hw, a_all=a16))
+        print(f"fused path: dense stack + conv1d #1 {t_conv3:.3f} ms, head without it {t_head3:.3f} ms")
 z, key = z.float(), key.float()
 off = batch.node_off()
 t_head, _ = T(lambda: seal.head(z, key, off, hw))

@@ -796,7 +796,7 @@ def test_seal_first_layer_from_tables(dev, sl, golden_dir):
         seal.first_layer_h1(batch, tag_map, T, emb[:300], w1[: T + 100])      # node ids >= 300 exist in the batch
 
 
-def test_seal_dense_conv_stack_matches_generic_at_scale(dev):
+def test_seal_dense_conv_stack_matches_generic_at_scale(dev, monkeypatch):
     """the dense-block MFMA conv stack against the generic CSR path on a hub-rich synthetic batch (236 K-node RMAT
     graph, 20 K candidate pairs, subgraphs of 2..100 vertices incl. capped ones, max_neighbors = 128 as well):
     every row of [Z1 | Z2 | Z3] and of the sort key within 2e-5."""
@@ -818,6 +818,17 @@ def test_seal_dense_conv_stack_matches_generic_at_scale(dev):
         zg, kg = seal.graph_conv_stack(g, d_inv, x, gw)
         zd, kd = seal.graph_conv_stack(None, None, x, gw, batch=batch)
         assert zd.shape == zg.shape and float((zd - zg).abs().max()) < 2e-5 and float((kd - kg).abs().max()) < 2e-5
+        # head fusion: conv1d #1 inside the conv stack == the concat times k1 afterwards; the concat is not written
+        k1 = torch.randn(96, 16, generator=gen, device=dev) * 0.2
+        a16, kf = seal.graph_conv_stack(None, None, x, gw, batch=batch, head_k1=k1)
+        want = zd.double() @ k1.double()
+        mag = zd.double().abs() @ k1.double().abs()
+        assert torch.equal(kf, kd) and a16.shape == (zd.shape[0], 16)
+        assert torch.all((a16.double() - want).abs() <= TOL * mag + 1e-30)
+        monkeypatch.setenv("LPG_SEAL_CONV_FP32", "1")          # the first formulation (fp32 MFMA) as the A/B reference
+        z32, k32 = seal.graph_conv_stack(None, None, x, gw, batch=batch)
+        monkeypatch.delenv("LPG_SEAL_CONV_FP32")
+        assert float((zd - z32).abs().max()) < 2e-5 and float((kd - k32).abs().max()) < 2e-5
 
 
 def test_seal_head_with_reference_weights(dev, sl, golden_dir):
