@@ -422,6 +422,7 @@ def test_localwl_small_path_matches_generic_path(dev, tw, monkeypatch):
     ei, pred, ei2 = t(tw["test_ei"]), t(tw["test_pred"]), t(tw["test_ei2"])
     x_deg = t(twowl_int.degree(tw["val_ei"].astype(np.int64), 620))
     pos1 = torch.cat([ei.t(), pred.t()], 0).contiguous()
+    monkeypatch.setattr(twowl, "_SMALL_PATH", True)            # whatever LPG_TWOWL_SMALL says in the environment
     for c1, c2, d1, d2 in [(256, 32, 1, 1), (32, 24, 2, 2)]:
         mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=c1, channels_2wl=c2, depth1=d1, depth2=d2).to(dev).eval()
         assert mod._small_graph_ok(x_deg, ei, pos1.shape[0])
@@ -802,6 +803,7 @@ def test_seal_dense_conv_stack_matches_generic_at_scale(dev, monkeypatch):
     every row of [Z1 | Z2 | Z3] and of the sort key within 2e-5."""
     import bench
     from lpgnn_amd import seal
+    monkeypatch.delenv("LPG_SEAL_CONV_FP32", raising=False)     # the default kernel is the one under test
     N, E = 235_868, 1_285_465
     ei = bench.rmat_edges(N, E, 1, dev)
     graph = seal.build_train_csr(ei.t().cpu().numpy(), N, test_ratio=0.0, device=dev)
