@@ -72,6 +72,6 @@ for _ in range(it):
 torch.cuda.synchronize()
 dt_struct = (time.time() - t0) / it
 print(json.dumps({"workload": f"synthetic collab-shaped SEAL: |V|={N} undirected |E|={E}, {B} candidate pairs, d={D} " + ("bf16 storage" if BF16 else "fp32"),
-                  "tags_size": T, "total_vertices": int(batch.n.sum()), "block_csr_nnz": g.nnz(),
+                  "tags_size": T, "total_vertices": int(batch.n.sum()), "block_csr_nnz": (g.nnz() if g is not None else None),
                   "capped_pairs": int(batch.capped.sum()), "ms_total": dt * 1e3, "ms_structure_and_inputs": dt_struct * 1e3,
                   "scored_edges_per_s": B / dt}))
