@@ -797,6 +797,32 @@ def test_seal_first_layer_from_tables(dev, sl, golden_dir):
         seal.first_layer_h1(batch, tag_map, T, emb[:300], w1[: T + 100])      # node ids >= 300 exist in the batch
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 130])
+def test_seal_dense_conv_stack_tiny_batches(dev, sl, B, monkeypatch):
+    """the dense conv stack on batches of 1..130 candidate pairs (one row window, windows that own nothing, a last
+    tile that is mostly padding): concat, sort key and the fused conv1d #1 against the generic CSR path."""
+    from lpgnn_amd import seal
+    monkeypatch.delenv("LPG_SEAL_CONV_FP32", raising=False)
+    pos = sl["positive"].astype(np.int64)
+    graph = seal.build_train_csr(pos, 620, test_ratio=0.1, device=dev)
+    rng = np.random.default_rng(B)
+    pairs = torch.from_numpy(np.concatenate([pos[:B // 2 + 1], rng.integers(0, 620, size=(B, 2))])[:B]).to(dev)
+    batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=3)
+    tag_map, T = seal.compact_tag_map(batch)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(B)
+    emb = torch.randn((620, 32 - T), generator=gen, device=dev)
+    gw = [torch.randn(a, b, generator=gen, device=dev) * s for a, b, s in ((32, 32, 0.3), (32, 32, 0.4), (32, 32, 0.4), (32, 1, 0.5))]
+    g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb)
+    zg, kg = seal.graph_conv_stack(g, d_inv, x, gw)
+    zd, kd = seal.graph_conv_stack(None, None, x, gw, batch=batch)
+    assert zd.shape == zg.shape and float((zd - zg).abs().max()) < 2e-5 and float((kd - kg).abs().max()) < 2e-5
+    k1 = torch.randn(96, 16, generator=gen, device=dev) * 0.2
+    a16, kf = seal.graph_conv_stack(None, None, x, gw, batch=batch, head_k1=k1)
+    want = zd.double() @ k1.double()
+    assert torch.equal(kf, kd) and float((a16.double() - want).abs().max()) < 2e-5
+
+
 def test_seal_dense_conv_stack_matches_generic_at_scale(dev, monkeypatch):
     """the dense-block MFMA conv stack against the generic CSR path on a hub-rich synthetic batch (236 K-node RMAT
     graph, 20 K candidate pairs, subgraphs of 2..100 vertices incl. capped ones, max_neighbors = 128 as well):
