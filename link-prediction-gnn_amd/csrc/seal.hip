@@ -112,13 +112,14 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_graph, const int64_t* __restrict__ pairs,
     int64_t B, int hop, int max_nb, int replay, int cap_policy, uint64_t seed, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
     int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag,
-    uint8_t* __restrict__ tag_present) {
+    uint8_t* __restrict__ tag_present, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
+    int hub_words) {
   __shared__ int32_t cand[2 * MAXN];
   __shared__ int32_t nodes[MAXN];
   __shared__ uint32_t adj[MAXN][WORDS];
   __shared__ int dist0[MAXN], dist1[MAXN];
   __shared__ uint32_t vis[2 * WORDS], fr[2 * WORDS], nx[2 * WORDS];
-  __shared__ int s_n, s_capped, s_cnt[2], s_nbig;
+  __shared__ int s_n, s_capped, s_cnt[2], s_nbig, s_search;
   __shared__ ListPlan s_list[2];
   __shared__ int64_t rbase[MAXN];                  // per subgraph vertex: its neighbour list in the big graph
   __shared__ int rdeg[MAXN];
@@ -360,7 +361,29 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     // subgraph has ~30 hubs = 1000 searches of ~12 dependent probes each, 8 per thread back to back before.
     // Without a replayed list only a <= b of the (symmetric) hub x hub block is searched and mirrored.
     const int nbig = s_nbig, ncol = replay ? n : nbig;
-    for (int p0 = t; p0 < nbig * ncol; p0 += 2 * kSealBlock) {
+    // With the graph's hub bit matrix (hub_index[node] = its row, -1 for a node that is not a hub; one bit per hub
+    // pair) a hub x hub entry is two index loads and one word instead of a ~12-probe binary search in a list of
+    // thousands.  A big row whose node has no hub index (tables built with another threshold) falls back to the search.
+    bool search = true;
+    if (hub_index && !replay) {
+      if (t == 0) s_search = 0;
+      __syncthreads();
+      for (int p = t; p < nbig * nbig; p += kSealBlock) {
+        const int a = p / nbig, b2 = p - a * nbig;
+        if (a > b2) continue;
+        const int i = big[a], j = big[b2];
+        const int ia = hub_index[nodes[i]], ib = hub_index[nodes[j]];
+        if (ia < 0 || ib < 0) { s_search = 1; continue; }
+        const uint32_t wbits = hub_bits[static_cast<int64_t>(ia) * hub_words + (ib >> 5)];
+        if (((wbits >> (ib & 31)) & 1u) && !((i == 0 && j == 1) || (i == 1 && j == 0))) {
+          atomicOr(&adj[i][j >> 5], 1u << (j & 31));
+          atomicOr(&adj[j][i >> 5], 1u << (i & 31));
+        }
+      }
+      __syncthreads();
+      search = s_search != 0;
+    }
+    for (int p0 = t; search && p0 < nbig * ncol; p0 += 2 * kSealBlock) {
       int lo[2], hi[2], len[2], ii[2], jj[2];
       int32_t key[2];
       const int32_t* row[2];
@@ -709,7 +732,8 @@ __global__ __launch_bounds__(kBlock) void softmax2_kernel(const float* __restric
 LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
                                   const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
                                   int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits, uint8_t* capped,
-                                  uint8_t* tag_present, int32_t* err_flag, void* stream) {
+                                  uint8_t* tag_present, const int32_t* hub_index, const uint32_t* hub_bits,
+                                  int64_t hub_words, int32_t* err_flag, void* stream) {
   LPG_REQUIRE(B >= 0 && n_graph_nodes >= 0, "seal_subgraphs: bad sizes");
   LPG_REQUIRE(hop == 0 || hop == 1, "seal_subgraphs: hop must be 0 or 1 (the reference itself fails for hop >= 2)");
   LPG_REQUIRE(max_neighbors >= 2 && max_neighbors <= MAXN, "seal_subgraphs: max_neighbors must be in [2, %d]", MAXN);
@@ -718,7 +742,7 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
   hipLaunchKernelGGL(seal_subgraph_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), adj_rowptr, adj_col,
                      n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag,
-                     tag_present);
+                     tag_present, hub_bits ? hub_index : nullptr, hub_bits, static_cast<int>(hub_words));
   return check_launch("seal_subgraphs");
 }
 

@@ -27,6 +27,38 @@ class TrainGraph:
 
     def __init__(self, rowptr, col, n_nodes):
         self.rowptr, self.col, self.n_nodes = rowptr, col, int(n_nodes)
+        self.hub_index = self.hub_bits = None        # hub bit matrix (build_hub_matrix): hub x hub adjacency in one load
+
+    HUB_DEGREE = 256                                 # the extraction kernel streams shorter neighbour lists
+    MAX_HUBS = 4096                                  # 2 MB of bits
+
+    def build_hub_matrix(self):
+        """hub_index[node] = row in the bit matrix (-1: not a hub), hub_bits[row, c >> 5] bit (c & 31) = hubs row and c
+        are adjacent; hubs = nodes with more than HUB_DEGREE neighbours.  Skipped for graphs with more than
+        MAX_HUBS of them (the kernel then binary-searches hub x hub entries as before)."""
+        dev = self.rowptr.device
+        deg = self.rowptr[1:] - self.rowptr[:-1]
+        hubs = torch.nonzero(deg > self.HUB_DEGREE).flatten()
+        H = int(hubs.numel())
+        if H == 0 or H > self.MAX_HUBS:
+            return self
+        idx = torch.full((self.n_nodes,), -1, dtype=torch.int32, device=dev)
+        idx[hubs] = torch.arange(H, dtype=torch.int32, device=dev)
+        W = (H + 31) // 32
+        dense = torch.zeros((H, W * 32), dtype=torch.bool, device=dev)
+        lens = deg[hubs]
+        rows = torch.repeat_interleave(torch.arange(H, device=dev), lens)
+        starts = torch.repeat_interleave(self.rowptr[hubs], lens)
+        offs = torch.arange(int(lens.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+        cols = idx[self.col[starts + offs].long()].long()
+        keep = cols >= 0
+        dense[rows[keep], cols[keep]] = True
+        weights = (torch.ones(32, dtype=torch.int64, device=dev) << torch.arange(32, device=dev))
+        words = (dense.view(H, W, 32).to(torch.int64) * weights).sum(-1)
+        self.hub_index = idx
+        self.hub_bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()   # uint32 bit patterns
+        self.hub_words = W
+        return self
 
 
 def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
@@ -39,7 +71,7 @@ def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
     col = (keys - rows * n_nodes).to(torch.int32)
     rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=device)
     rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n_nodes), 0)
-    return TrainGraph(rowptr, col.contiguous(), n_nodes)
+    return TrainGraph(rowptr, col.contiguous(), n_nodes).build_hub_matrix()
 
 
 class SubgraphBatch:
@@ -98,6 +130,8 @@ def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, r
                                       B, int(hop), int(max_neighbors), int(replay), CAP_POLICY[cap_policy],
                                       int(seed) & 0xFFFFFFFFFFFFFFFF, _ops._ptr(nodes), _ops._ptr(n),
                                       _ops._ptr(tags), _ops._ptr(adj_bits), _ops._ptr(capped), _ops._ptr(present),
+                                      _ops._ptr(graph.hub_index), _ops._ptr(graph.hub_bits),
+                                      getattr(graph, "hub_words", 0) if graph.hub_bits is not None else 0,
                                       _ops._ptr(_ops.err_flag(dev)), _ops._stream()), "seal_subgraphs")
     _ops.maybe_check(dev, "candidate pair / node id")
     return SubgraphBatch(pairs, nodes, n, tags, adj_bits, capped, present)

@@ -797,6 +797,42 @@ def test_seal_first_layer_from_tables(dev, sl, golden_dir):
         seal.first_layer_h1(batch, tag_map, T, emb[:300], w1[: T + 100])      # node ids >= 300 exist in the batch
 
 
+def test_seal_hub_bit_matrix_matches_searches(dev):
+    """the per-graph hub bit matrix (hub x hub adjacency = one load) against the binary searches it replaces: every
+    output of the extraction identical on a hub-rich RMAT graph; the matrix itself against the CSR."""
+    import bench
+    from lpgnn_amd import seal
+    N, E = 235_868, 1_285_465
+    ei = bench.rmat_edges(N, E, 1, dev)
+    graph = seal.build_train_csr(ei.t().cpu().numpy(), N, test_ratio=0.0, device=dev)
+    assert graph.hub_bits is not None and graph.hub_index is not None
+    H = graph.hub_bits.shape[0]
+    deg = graph.rowptr[1:] - graph.rowptr[:-1]
+    assert H == int((deg > seal.TrainGraph.HUB_DEGREE).sum()) and H > 10
+    hubs = torch.nonzero(graph.hub_index >= 0).flatten()
+    rng = np.random.default_rng(0)
+    bits = _np(graph.hub_bits).view(np.uint32)
+    rp, cl = _np(graph.rowptr), _np(graph.col)
+    hub_nodes = _np(hubs)
+    for a in rng.integers(0, H, size=40):
+        nb = set(cl[rp[hub_nodes[a]]:rp[hub_nodes[a] + 1]].tolist())
+        for b in rng.integers(0, H, size=40):
+            assert bool((bits[a, b >> 5] >> (b & 31)) & 1) == (int(hub_nodes[b]) in nb)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(9)
+    pairs = torch.randint(0, N, (20_000, 2), generator=gen, device=dev)
+    pairs[:2000, 0] = hubs[torch.randint(0, H, (2000,), generator=gen, device=dev)]       # hub-rich subgraphs
+    with_m = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=5)
+    plain = seal.TrainGraph(graph.rowptr, graph.col, N)                                    # no matrix: searches
+    without = seal.extract_subgraphs(pairs, plain, 1, cap_policy="device", seed=5)
+    for f in ("n", "nodes", "tags", "adj_bits", "capped", "tag_present"):
+        a, b = getattr(with_m, f), getattr(without, f)
+        if f in ("nodes", "tags", "adj_bits"):                 # rows beyond n are unspecified
+            m = (torch.arange(128, device=dev)[None, :] < with_m.n[:, None].long())
+            a, b = a[m], b[m]
+        assert torch.equal(a, b), f
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 130])
 def test_seal_dense_conv_stack_tiny_batches(dev, sl, B, monkeypatch):
     """the dense conv stack on batches of 1..130 candidate pairs (one row window, windows that own nothing, a last
