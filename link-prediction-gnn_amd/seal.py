@@ -412,18 +412,43 @@ def sortpool(z, key, node_off, k):
     return out
 
 
+_fold_cache = {}
+
+
+def _folded_conv2_dense(hw, k):
+    """[k * c1, dense] matrix of conv1d #2 (SEAL/model/gnn.py:113-118) composed with weight_1 (:124-129):
+    Wc[(t + dt) * c1 + i, j] += sum_c K2[dt, i, c] * W1[t * c2 + c, j] for every window t and tap dt.
+    Weight preprocessing, done once per (weights, version) in fp64 and rounded to fp32."""
+    k2, w1 = hw["conv1d_kernel_2"], hw["weight_1"]
+    key = (k2.data_ptr(), k2._version, w1.data_ptr(), w1._version, k)
+    hit = _fold_cache.get(key)
+    if hit is not None:
+        return hit[0]
+    fw, c1, c2 = k2.shape
+    t_out = k - fw + 1
+    w1r = w1.double().view(t_out, c2, -1)                               # [t, c, j]
+    wc = torch.zeros((k, c1, w1.shape[1]), dtype=torch.float64, device=w1.device)
+    for dt in range(fw):
+        wc[dt:dt + t_out] += torch.einsum("ic,tcj->tij", k2[dt].double(), w1r)
+    out = wc.view(k * c1, -1).float().contiguous()
+    if len(_fold_cache) > 8:
+        _fold_cache.clear()
+    _fold_cache[key] = (out, k2, w1)                                    # keeps the key tensors alive
+    return out
+
+
 def head(z, key, node_off, hw, a_all=None):
     """The DGCNN head of SEAL/model/gnn.py:82-137, batched over all subgraphs:
     SortPooling -> conv1d(96->16, stride 96) -> conv1d(width 5, 16->32) -> dense 128 relu -> dense 2
-    -> softmax.  Every stage is one launch on the whole batch; the two 1-D convolutions are matmuls
-    over (overlapping) row windows of the previous buffer, so nothing is gathered or copied.
+    -> softmax.  Every stage is one launch on the whole batch.  Neither convolution has an activation: conv1d #1
+    is a per-vertex linear applied BEFORE the pooling (or inside the conv stack), conv1d #2 is folded into the
+    dense layer's matrix.
     hw: dict with conv1d_kernel_1 [96,1,16], conv1d_kernel_2 [5,16,32], weight_1 [448,128], bias_1,
     weight_2 [128,2], bias_2 (the shipped checkpoint's tensors).  Returns (pre_y [B,2], score [B]).
     a_all: z @ conv1d_kernel_1 [total, 16] when the conv stack already produced it (graph_conv_stack(head_k1=));
     z may then be None."""
     lib = _lib.load()
     k1 = hw["conv1d_kernel_1"].reshape(-1, hw["conv1d_kernel_1"].shape[-1])          # [96, 16]
-    k2 = hw["conv1d_kernel_2"].reshape(-1, hw["conv1d_kernel_2"].shape[-1])          # [80, 32] (dt-major)
     fw, c1, c2 = hw["conv1d_kernel_2"].shape
     k = hw["weight_1"].shape[0] // c2 + fw - 1                                           # threshold_k (18)
     B = node_off.numel() - 1
@@ -432,12 +457,11 @@ def head(z, key, node_off, hw, a_all=None):
     # first moves 16-float rows through the pooling instead of 96-float ones (1.25 GB less traffic per 100 K subgraphs).
     if a_all is None:
         a_all = _ops.linear(z, k1, w_is_km=True)
-    a = sortpool(a_all, key, node_off, k).view(B * k, -1)                                # [B*k, 16]
-    # rows t >= k - fw + 1 of a subgraph's block are windows that run into the next subgraph; the dense layer below
-    # reads only the first (k - fw + 1) * c2 values of each block, so they (and the unwritten tail) are never used
-    c = torch.empty((B * k, c2), dtype=torch.float32, device=a.device)
-    _ops.linear(a, k2, w_is_km=True, n=B * k - (fw - 1), ldx=c1, out=c[: B * k - (fw - 1)])   # windows t..t+4
-    dense = _ops.linear(c, hw["weight_1"], hw["bias_1"], w_is_km=True, act="relu", n=B, ldx=k * c2)
+    a = sortpool(a_all, key, node_off, k).view(B, k * c1)                                # [B, k*16]
+    # conv1d #2 (width 5, stride 1, VALID) has NO activation and neither has the flatten: conv1d #2 followed by the
+    # dense layer is ONE linear map from the pooled [k, 16] block to the 128 dense units.  Its matrix is folded once
+    # per set of weights; the [B*k, 32] convolution output (230 MB per 100 K subgraphs) is never formed.
+    dense = _ops.linear(a, _folded_conv2_dense(hw, k), hw["bias_1"], w_is_km=True, act="relu")
     pre_y = _ops.linear(dense, hw["weight_2"], hw["bias_2"], w_is_km=True)
     score = torch.empty(B, dtype=torch.float32, device=a.device)
     _lib.check(lib.lpg_softmax2_pos_score_f32(_ops._ptr(pre_y), B, _ops._ptr(score), _ops._stream()), "softmax2")
