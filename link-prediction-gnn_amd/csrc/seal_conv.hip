@@ -262,14 +262,23 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
 
   // ---- everything that depends on nothing but the window: H_1 planes, the bit table, the weight operands
   // rows [nrows, 32 ntiles) are zero (their adjacency entries are zero, but 0 x NaN is not)
-  for (int idx = tid; idx < ntiles * 32 * 32; idx += kConvBlock) {
-    const int row = idx >> 5, c = idx & 31;
-    const float v = row < nrows ? h1[(r_lo + row) * ldh + c] : 0.f;
-    uint32_t a0, a1, a2;
-    split3(v, a0, a1, a2);
-    Hp[0][c][row] = static_cast<uint16_t>(a0);
-    Hp[1][c][row] = static_cast<uint16_t>(a1);
-    Hp[2][c][row] = static_cast<uint16_t>(a2);
+  {
+    // lanes walk ROW PAIRS of one feature: the three plane words of a pair are whole dwords and consecutive lanes hit
+    // consecutive banks (lanes walking the features of one row wrote 2-byte pieces 528 bytes apart: 4-way bank
+    // conflicts on 48 writes per thread -- set-up was a third of the kernel); the strided global reads hit in L1
+    // (the window's rows are 16-32 KB and every line is used by all 32 features)
+    const int R2 = ntiles * 16;                       // row pairs
+    for (int idx = tid; idx < R2 * 32; idx += kConvBlock) {
+      const int c = idx / R2, rp = idx - c * R2, row = 2 * rp;
+      const float v0 = row < nrows ? h1[(r_lo + row) * ldh + c] : 0.f;
+      const float v1 = row + 1 < nrows ? h1[(r_lo + row + 1) * ldh + c] : 0.f;
+      uint32_t a0, a1, a2, b0, b1, b2;
+      split3(v0, a0, a1, a2);
+      split3(v1, b0, b1, b2);
+      *reinterpret_cast<uint32_t*>(&Hp[0][c][row]) = a0 | (b0 << 16);
+      *reinterpret_cast<uint32_t*>(&Hp[1][c][row]) = a1 | (b1 << 16);
+      *reinterpret_cast<uint32_t*>(&Hp[2][c][row]) = a2 | (b2 << 16);
+    }
   }
   {                                                 // byte -> 8 bf16 (bit j set -> 1.0 = 0x3F80 in element j)
     uint32_t d[4];
@@ -404,6 +413,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
       f32x16 hn;
 #pragma unroll
       for (int i = 0; i < 16; ++i) hn[i] = 0.f;
+      const bool merged = k1 && layer == 3;          // 32 -> 1 (w4) rides in row 16 of the conv1d #1 product: 17 <= 32 rows
       if (layer < 3) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
           hn = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, z[4 * g + 2], hn, 0, 0, 0);
           hn = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, z[4 * g + 3], hn, 0, 0, 0);
         }
-      } else {                                       // 32 -> 1: only output row o = 0 is non-zero
+      } else if (!merged) {                          // 32 -> 1: only output row o = 0 is non-zero
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float wv = r == 0 ? w4[acc_row(i, h)] : 0.f;
@@ -427,6 +437,8 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
         for (int g = 0; g < 4; ++g) {
           float4 kv = *reinterpret_cast<const float4*>(&Kl[layer - 1][g][h][r & 15][0]);
           if (r >= 16) kv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (merged && r == 16)                     // row 16 = the layer-4 input feature 0 (accumulator register 8, h = 0)
+            kv = make_float4(w4[acc_row(4 * g + 0, h)], w4[acc_row(4 * g + 1, h)], w4[acc_row(4 * g + 2, h)], w4[acc_row(4 * g + 3, h)]);
           aa = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, z[4 * g + 0], aa, 0, 0, 0);
           aa = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, z[4 * g + 1], aa, 0, 0, 0);
           aa = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, z[4 * g + 2], aa, 0, 0, 0);
@@ -445,6 +457,18 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
     for (int t = 0; t < 2; ++t) {
       const int I = wave + t * (kConvBlock / 64);
       if (I >= ntiles) continue;
+      if (k1 && layer == 3) {
+        // layer 4 reads feature 0 only (the sort key): it sits in row 16 of the merged product; the other features'
+        // planes keep layer 3's values, whose output rows nobody reads
+        if (h == 0) {
+          uint32_t ph, pm, pl;
+          split3(t == 0 ? aa0[8] : aa1[8], ph, pm, pl);
+          Hp[0][0][32 * I + r] = static_cast<uint16_t>(ph);
+          Hp[1][0][32 * I + r] = static_cast<uint16_t>(pm);
+          Hp[2][0][32 * I + r] = static_cast<uint16_t>(pl);
+        }
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {                 // lane = vertex 32 I + r, register i = feature acc_row(i, h)
         uint32_t ph, pm, pl;
