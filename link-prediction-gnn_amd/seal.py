@@ -35,8 +35,10 @@ class TrainGraph:
     def build_hub_matrix(self):
         """hub_index[node] = row in the bit matrix (-1: not a hub), hub_bits[row, c >> 5] bit (c & 31) = hubs row and c
         are adjacent; hubs = nodes with more than HUB_DEGREE neighbours.  Skipped for graphs with more than
-        MAX_HUBS of them (the kernel then binary-searches hub x hub entries as before)."""
+        MAX_HUBS of them or fewer than 128 K stored edges (the kernel then binary-searches hub x hub entries as before)."""
         dev = self.rowptr.device
+        if self.col.numel() < (1 << 17):             # small graphs (fb-pages-food): no host sync, the few searches are cheap
+            return self
         deg = self.rowptr[1:] - self.rowptr[:-1]
         hubs = torch.nonzero(deg > self.HUB_DEGREE).flatten()
         H = int(hubs.numel())
