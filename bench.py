@@ -194,7 +194,7 @@ def seal_forward_bench(device, iters=10):
         return seal.link2subgraph(pos, neg, 620, 0.1, 1, device=device)
 
     def aggregate(batch, tag_map, T):
-        h1 = seal.first_layer_h1(batch, tag_map, T, emb, weights[0])               # X W_1 from two row gathers, X never built
+        h1 = seal.first_layer_h1(batch, tag_map, T, emb, weights[0], check=False)  # X W_1 from two row gathers, X never built
         a16, key = seal.graph_conv_stack(None, None, None, weights, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
         return seal.head(None, key, batch.node_off(), hw, a_all=a16)[1]       # P(link) per candidate
 
@@ -249,7 +249,7 @@ def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5
 
     def score_fn(p):
         batch = seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=0)
-        h1 = seal.first_layer_h1(batch, tag_map, T, emb, gw[0])                    # X W_1 from two row gathers, X never built
+        h1 = seal.first_layer_h1(batch, tag_map, T, emb, gw[0], check=False)       # X W_1 from two row gathers, X never built
         a16, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
         return seal.head(None, key, batch.node_off(), hw, a_all=a16)[1]
 

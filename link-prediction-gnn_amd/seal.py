@@ -85,9 +85,18 @@ class SubgraphBatch:
         self._total = None
 
     def total(self):
-        """number of vertices in the batch (one host sync, cached)."""
+        """number of vertices in the batch (one host sync, cached).  The extraction's index check rides on the same
+        transfer: the error flag comes back with the total instead of in a sync of its own."""
         if self._total is None:
-            self._total = int(self.node_off()[-1].item())
+            off = self.node_off()
+            if _ops._CHECK and not torch.cuda.is_current_stream_capturing():
+                both = torch.stack([off[-1], _ops.err_flag(off.device)[0].to(torch.int64)]).tolist()
+                self._total = int(both[0])
+                if both[1]:
+                    _ops.err_flag(off.device).zero_()
+                    raise IndexError(f"lpgnn_amd: candidate pair / node id out of range (flag={int(both[1])})")
+            else:
+                self._total = int(off[-1].item())
         return self._total
 
     def node_off(self):
@@ -135,7 +144,8 @@ def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, r
                                       _ops._ptr(graph.hub_index), _ops._ptr(graph.hub_bits),
                                       getattr(graph, "hub_words", 0) if graph.hub_bits is not None else 0,
                                       _ops._ptr(_ops.err_flag(dev)), _ops._stream()), "seal_subgraphs")
-    _ops.maybe_check(dev, "candidate pair / node id")
+    # no sync of its own: the flag is read together with the batch's vertex total (SubgraphBatch.total(), which every
+    # consumer needs first) or by the next checking op; out-of-range pairs were skipped, never dereferenced
     return SubgraphBatch(pairs, nodes, n, tags, adj_bits, capped, present)
 
 
@@ -326,7 +336,7 @@ def _block_csr(lib, batch, off, total, fold_dinv):
 _p_table_cache = {}
 
 
-def first_layer_h1(batch, tag_map, tags_size, emb, w1):
+def first_layer_h1(batch, tag_map, tags_size, emb, w1, check=True):
     """H_1 = X W_1 for X = [onehot(tag) || emb[node]] WITHOUT building X (SEAL/config/data.py:129-140 +
     SEAL/model/gnn.py:46): a one-hot row times W_1 is a row of W_1, and emb[node] @ W_1[T:] is row `node` of
     P = emb @ W_1[T:] (one small matmul), so H_1[g] = W_1[tag_g] + P[node_g].  fp32, W_1 [T + dim, 32]."""
@@ -352,7 +362,8 @@ def first_layer_h1(batch, tag_map, tags_size, emb, w1):
     _lib.check(lib.lpg_seal_h1_tables_f32(P(batch.nodes), P(off), P(batch.tags), P(tag_map), tag_map.numel(), T,
                                           P(w1_tag), P(p_table), emb.shape[0], batch.B, P(h1), h1.stride(0),
                                           P(_ops.err_flag(emb.device)), _ops._stream()), "seal_h1_tables")
-    _ops.maybe_check(emb.device, "seal first-layer index")
+    if check:                                         # check=False: the flag is read by the next checking op (head())
+        _ops.maybe_check(emb.device, "seal first-layer index")
     return h1
 
 
@@ -478,6 +489,7 @@ def head(z, key, node_off, hw, a_all=None):
     pre_y = _ops.linear(dense, hw["weight_2"], hw["bias_2"], w_is_km=True)
     score = torch.empty(B, dtype=torch.float32, device=a.device)
     _lib.check(lib.lpg_softmax2_pos_score_f32(_ops._ptr(pre_y), B, _ops._ptr(score), _ops._stream()), "softmax2")
+    _ops.maybe_check(a.device, "seal forward index")       # the one deferred check of the scoring forward
     return pre_y, score
 
 
@@ -489,7 +501,7 @@ def score_links(positive, negative, nodes_size, emb, weights, head_weights, test
         k1 = head_weights["conv1d_kernel_1"]
         k1 = k1.reshape(-1, k1.shape[-1])
         fuse = tuple(k1.shape) == (96, 16) and os.environ.get("LPG_SEAL_CONV_FP32", "0") == "0"
-        h1 = first_layer_h1(batch, tag_map, T, emb, weights[0])
+        h1 = first_layer_h1(batch, tag_map, T, emb, weights[0], check=False)       # head() reads the flag at the end
         z, key = graph_conv_stack(None, None, None, weights, batch=batch, h1=h1, head_k1=k1 if fuse else None)
         _, score = head(None if fuse else z, key, batch.node_off(), head_weights, a_all=z if fuse else None)
         return score, labels, batch

@@ -797,6 +797,19 @@ def test_seal_first_layer_from_tables(dev, sl, golden_dir):
         seal.first_layer_h1(batch, tag_map, T, emb[:300], w1[: T + 100])      # node ids >= 300 exist in the batch
 
 
+def test_seal_out_of_range_pair_is_flagged_with_the_total(dev, sl):
+    """a candidate pair outside the graph is skipped by the extraction kernel (n = 0) and surfaces as IndexError at
+    the batch's first host read -- SubgraphBatch.total(), which every consumer needs -- not in a sync of its own."""
+    from lpgnn_amd import seal
+    graph = seal.build_train_csr(sl["positive"].astype(np.int64), 620, test_ratio=0.1, device=dev)
+    pairs = torch.tensor([[1, 2], [3, 700], [4, 5]], device=dev)
+    batch = seal.extract_subgraphs(pairs, graph, 1)
+    with pytest.raises(IndexError):
+        batch.total()
+    ok = seal.extract_subgraphs(pairs[[0, 2]], graph, 1)
+    assert ok.total() == int(ok.n.sum()) and int(batch.n[1]) == 0
+
+
 def test_seal_hub_bit_matrix_matches_searches(dev):
     """the per-graph hub bit matrix (hub x hub adjacency = one load) against the binary searches it replaces: every
     output of the extraction identical on a hub-rich RMAT graph; the matrix itself against the CSR."""
