@@ -165,8 +165,11 @@ __global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restric
 // them in fp64 (per thread in row order, then a fixed shuffle / LDS tree), derives shift / scale / bias, and
 // applies them to the registers.  The fb-pages-food forward calls GraphNorm four times on [620..6576, 32..256]
 // tensors and is launch-bound: one launch instead of three saves ~9 us per call.
-constexpr int kSmallRows = 8;        // rows per thread
+constexpr int kSmallRowsMax = 8;     // rows per thread, at most
 constexpr int kSmallBlock = 1024;
+// kSmallRows = rows per thread actually needed (1 for n <= 1024, ...): the loads of absent rows are clamped duplicates,
+// and at fb-pages-food's 620 rows seven of eight were
+template <int kSmallRows>
 __global__ __launch_bounds__(kSmallBlock) void gn_small_kernel(const float* __restrict__ x, int n, int d,
                                                               const float* __restrict__ weight,
                                                               const float* __restrict__ bias,
@@ -262,6 +265,15 @@ __global__ __launch_bounds__(kSmallBlock) void gn_small_kernel(const float* __re
   }
 }
 
+template <typename... A>
+inline void launch_gn_small(dim3 grid, hipStream_t st, const float* x, int n, A... rest) {
+  const int rows = (n + kSmallBlock - 1) / kSmallBlock;          // rows per thread actually present
+  if (rows <= 1) hipLaunchKernelGGL(gn_small_kernel<1>, grid, dim3(kSmallBlock), 0, st, x, n, rest...);
+  else if (rows <= 2) hipLaunchKernelGGL(gn_small_kernel<2>, grid, dim3(kSmallBlock), 0, st, x, n, rest...);
+  else if (rows <= 4) hipLaunchKernelGGL(gn_small_kernel<4>, grid, dim3(kSmallBlock), 0, st, x, n, rest...);
+  else hipLaunchKernelGGL(gn_small_kernel<8>, grid, dim3(kSmallBlock), 0, st, x, n, rest...);
+}
+
 inline int part_blocks(int64_t n, int64_t* rows_per_block) {
   int64_t rpb = ceil_div(n, kMaxPartBlocks);
   if (rpb < 8) rpb = 8;           // small n: many short blocks (each thread's row loop is a latency chain)
@@ -289,11 +301,11 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
   {
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
     const char* env = getenv("LPG_GN_SMALL");          // A/B hook: 0 keeps the three-launch path
-    if (n <= kSmallRows * kSmallBlock && d % 4 == 0 && d / 4 < 65536 && al16(x) && al16(y) && (!add_to || al16(add_to)) &&
+    if (n <= kSmallRowsMax * kSmallBlock && d % 4 == 0 && d / 4 < 65536 && al16(x) && al16(y) && (!add_to || al16(add_to)) &&
         !(env && atoi(env) == 0)) {
-      hipLaunchKernelGGL(gn_small_kernel, dim3(static_cast<unsigned>(d / 4)), dim3(kSmallBlock), 0, st, x,
-                         static_cast<int>(n), static_cast<int>(d), weight, bias, mean_scale, eps, relu, add_to, y,
-                         static_cast<const int64_t*>(nullptr), 0, static_cast<int32_t*>(nullptr));
+      launch_gn_small(dim3(static_cast<unsigned>(d / 4)), st, x, static_cast<int>(n), static_cast<int>(d), weight, bias,
+                      mean_scale, eps, relu, add_to, y, static_cast<const int64_t*>(nullptr), 0,
+                      static_cast<int32_t*>(nullptr));
       return check_launch("graphnorm (one launch)");
     }
   }
@@ -324,12 +336,12 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
 LPG_EXPORT int lpg_embedding_graphnorm_f32(const float* table, int64_t n_table, int64_t d, const int64_t* idx, int64_t n,
                                            const float* weight, const float* bias, const float* mean_scale, float eps,
                                            int relu, float* y, int32_t* err_flag, void* stream) {
-  LPG_REQUIRE(n >= 1 && n <= kSmallRows * kSmallBlock && d >= 4 && d % 4 == 0 && d / 4 < 65536 && n_table >= 1,
-              "embedding_graphnorm: needs 1 <= n <= %d rows and d %% 4 == 0", kSmallRows * kSmallBlock);
+  LPG_REQUIRE(n >= 1 && n <= kSmallRowsMax * kSmallBlock && d >= 4 && d % 4 == 0 && d / 4 < 65536 && n_table >= 1,
+              "embedding_graphnorm: needs 1 <= n <= %d rows and d %% 4 == 0", kSmallRowsMax * kSmallBlock);
   LPG_REQUIRE(table && idx && y && reinterpret_cast<uintptr_t>(table) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0,
               "embedding_graphnorm: null or misaligned pointer");
-  hipLaunchKernelGGL(gn_small_kernel, dim3(static_cast<unsigned>(d / 4)), dim3(kSmallBlock), 0, as_stream(stream), table,
-                     static_cast<int>(n), static_cast<int>(d), weight, bias, mean_scale, eps, relu,
-                     static_cast<const float*>(nullptr), y, idx, static_cast<int>(n_table), err_flag);
+  launch_gn_small(dim3(static_cast<unsigned>(d / 4)), as_stream(stream), table, static_cast<int>(n), static_cast<int>(d),
+                  weight, bias, mean_scale, eps, relu, static_cast<const float*>(nullptr), y, idx,
+                  static_cast<int>(n_table), err_flag);
   return check_launch("embedding_graphnorm");
 }

@@ -32,7 +32,6 @@ using namespace lpg;
 
 constexpr int kSgBlock = 1024;        // threads of the column workgroup = strips of the edge stream
 constexpr int kSgMaxRows = 8192;      // rows a column workgroup can hold (2 x 32 KB of LDS)
-constexpr int kSgRowsPerThread = kSgMaxRows / kSgBlock;
 constexpr int kSgMaxRowBlocks = 8;
 constexpr uint32_t kSgPad = 0xFFFFFFFFu;
 
@@ -277,6 +276,9 @@ struct SgSide {
   double* part;             // [rb][2][c] column sums of y and y^2 per row block
 };
 
+// RT = rows per thread of the LONGER of (all rows: the column fill) and nothing else -- ceil(n / 1024); absent rows are
+// clamped duplicate loads, and at 620 rows seven of eight were
+template <int RT>
 __global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const SgSide s1, int n, int rb, int64_t ldt,
                                                           int64_t ldo, int64_t cap_words) {
   __shared__ float hs[kSgMaxRows];
@@ -300,11 +302,11 @@ __global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const
   uint4 u[kBatch], un[kBatch];
 #pragma unroll
   for (int b = 0; b < kBatch; ++b) u[b] = pk[static_cast<int64_t>(b < q_cap ? b : q_cap - 1) * kSgBlock + t];
-  float dv[kSgRowsPerThread];
+  float dv[RT];
   {
-    float hv[kSgRowsPerThread], dd[kSgRowsPerThread];
+    float hv[RT], dd[RT];
 #pragma unroll
-    for (int i = 0; i < kSgRowsPerThread; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int r = t + i * kSgBlock;
       const int rc = r < n ? r : n - 1;
       hv[i] = s.hT[static_cast<int64_t>(c) * ldt + rc];
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const
       dv[i] = s.dinv[rl < n ? rl : n - 1];
     }
 #pragma unroll
-    for (int i = 0; i < kSgRowsPerThread; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int r = t + i * kSgBlock;
       if (r < n) hs[r] = hv[i] * dd[i];
       if (r < r1 - r0) acc[r] = 0.f;
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const
   // ---- dinv[row] * sum + bias -> y; the block's column sums for the deferred GraphNorm
   double ds = 0.0, ds2 = 0.0;
 #pragma unroll
-  for (int i = 0; i < kSgRowsPerThread; ++i) {
+  for (int i = 0; i < RT; ++i) {
     const int r = t + i * kSgBlock;
     if (r < r1 - r0) {
       const float y = fmaf(acc[r], dv[i], bias);
@@ -552,9 +554,16 @@ LPG_EXPORT int lpg_small_gcn_f32(int64_t n, int64_t c, int64_t ldt, int64_t ldo,
   SgSide s0{hT, static_cast<const uint32_t*>(pack), rowptr, dinv, bias, y, part};
   SgSide s1 = s0;
   if (two) s1 = SgSide{hT2, static_cast<const uint32_t*>(pack2), rowptr2, dinv2, bias2, y2, part2};
-  hipLaunchKernelGGL(sg_gcn_kernel, dim3(static_cast<unsigned>(c), static_cast<unsigned>(row_blocks), two ? 2 : 1),
-                     dim3(kSgBlock), 0, as_stream(stream), s0, s1, static_cast<int>(n), static_cast<int>(row_blocks), ldt,
-                     ldo, sg_strip(e_cap) * kSgBlock);
+  const dim3 grid(static_cast<unsigned>(c), static_cast<unsigned>(row_blocks), two ? 2 : 1);
+  const int rows = static_cast<int>((n + kSgBlock - 1) / kSgBlock);
+#define LPG_SG_GCN(RTV)                                                                                               \
+  hipLaunchKernelGGL(sg_gcn_kernel<RTV>, grid, dim3(kSgBlock), 0, as_stream(stream), s0, s1, static_cast<int>(n),     \
+                     static_cast<int>(row_blocks), ldt, ldo, sg_strip(e_cap) * kSgBlock)
+  if (rows <= 1) LPG_SG_GCN(1);
+  else if (rows <= 2) LPG_SG_GCN(2);
+  else if (rows <= 4) LPG_SG_GCN(4);
+  else LPG_SG_GCN(8);
+#undef LPG_SG_GCN
   return check_launch("small_gcn");
 }
 
