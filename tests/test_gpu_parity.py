@@ -552,6 +552,41 @@ def test_small_gcn_deferred_norm(dev, n, E, c, shape, rb, monkeypatch):
         assert got.shape == (50, 1) and np.abs(_np(got) - want).max() <= tol(want) * c
 
 
+def test_small_gcn_random_sweep(dev, monkeypatch):
+    """60 seeded random graphs (sizes, densities, hubs, duplicate edges, every row-block count) through
+    lpg_small_gcn_f32 against an fp64 scatter-add of the same normalised edges on the device: strip borders, pieces
+    and row blocks land everywhere."""
+    from lpgnn_amd import ops
+    from lpgnn_amd.nn import graph_cache
+    rng = np.random.default_rng(1234)
+    for trial in range(60):
+        n = int(rng.choice([2, 3, 17, 64, 333, 1024, 1025, 2500, 5000]))
+        E = int(rng.integers(0, 40 * n)) if n < 2000 else int(rng.integers(0, 12 * n))
+        c = int(rng.integers(1, 6))
+        rb = int(rng.choice([1, 2, 3, 4, 8]))
+        monkeypatch.setenv("LPG_SG_ROW_BLOCKS", str(rb))
+        ei = rng.integers(0, n, size=(2, E)).astype(np.int64)
+        if E and rng.random() < 0.4:
+            ei[1, : E // 3] = rng.integers(0, n)                       # a heavy row
+        ei_t = torch.from_numpy(ei).to(dev)
+        g = graph_cache.get(ei_t, None, n, True)
+        h = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(dev)
+        bias = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).to(dev)
+        ldt = (n + 3) // 4 * 4
+        hT = torch.zeros((c, ldt), dtype=torch.float32, device=dev)
+        hT[:, :n] = h.t()
+        out, = ops.small_gcn(n, [(hT, g, bias, None, False)])
+        nnz = g.nnz()
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), (g.rowptr[1:] - g.rowptr[:-1]))
+        cols = g.col[:nnz].long()
+        w = g.val[:nnz].double()
+        want = torch.zeros((n, c), dtype=torch.float64, device=dev).index_add_(0, rows, h.double()[cols] * w[:, None]) + bias.double()
+        mag = torch.zeros((n, c), dtype=torch.float64, device=dev).index_add_(0, rows, (h.double()[cols] * w[:, None]).abs()) + bias.double().abs()
+        assert torch.all((out.y.double() - want).abs() <= 4 * TOL * mag + 1e-30), (trial, n, E, c, rb)
+        assert torch.allclose(out.part[:, 0].sum(0), out.y.double().sum(0), rtol=1e-12, atol=1e-9)
+        assert torch.allclose(out.part[:, 1].sum(0), (out.y.double() ** 2).sum(0), rtol=1e-12, atol=1e-9)
+
+
 def test_embedding_graph_norm(dev):
     from lpgnn_amd import ops
     from oracle import aggregation as agg
