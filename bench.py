@@ -12,9 +12,11 @@ kernels of lpg_csr_spmm_f32) with graph, plan and X already resident in HBM.
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the north star's
 source-edge partition -- rank g owns source rows [g*V/N, (g+1)*V/N) of X and the |E| = 100 M
 edges that leave them (weak scaling: per-GPU edges fixed), computes a partial Y_g[V, d], and the
-partials are summed over xGMI with an RCCL reduce-scatter (default: every rank keeps the rows of
-its own range, which is what the next layer on the same partition reads; --collective all_reduce
-gives the full Y everywhere), pipelined in stages against the SpMM of the next stage.
+partials are summed over xGMI so that every rank keeps the rows of its own range (what the next layer on
+the same partition reads): by default only the NON-EMPTY rows of a partial travel (one variable-split RCCL
+all-to-all per stage, checked against the dense reduce-scatter before timing; --collective reduce_scatter
+forces the dense form, --collective all_reduce gives the full Y everywhere), pipelined in stages against
+the SpMM of the next stage.
 value = edges aggregated by ALL ranks per second (max-over-ranks time).
 
 Prints ONE JSON line (rank 0).  Extra objects: roofline (HBM, dominant kernel), cpu_baseline
@@ -308,8 +310,10 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--blocks", type=int, default=4, help="pipeline stages for compute/collective overlap (N > 1)")
-    ap.add_argument("--collective", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
-                    help="how the per-rank partial aggregates are summed (N > 1); see lpgnn_amd/dist.py")
+    ap.add_argument("--collective", default="auto", choices=["auto", "sparse", "reduce_scatter", "all_reduce"],
+                    help="how the per-rank partial aggregates are summed (N > 1); see lpgnn_amd/dist.py.  auto = the "
+                         "sparse exchange (only the non-empty rows of the partial travel) when fewer than 3/4 of the "
+                         "rows are non-empty and it reproduces the reduce-scatter on this graph, else reduce_scatter")
     ap.add_argument("--partition", default="source", choices=["source", "dst"],
                     help="source: the north star's source-edge partition + RCCL reduction (default). dst: every rank "
                          "owns the destination rows of its range and a replica of X -- no reduction at all (SURVEY 8e's "
@@ -368,6 +372,24 @@ def main():
         runner = ldist.SourcePartitionedSpMM(ei, N, (lo, hi), n_blocks=args.blocks, collective=args.collective)
         del ei
         g = None
+        if runner.collective == "sparse":
+            # self-check before anything is timed: the sparse exchange must reproduce the dense reduce-scatter on this
+            # very graph, on every rank; if not (or if it raises), every rank falls back to the reduce-scatter
+            ok = 1
+            try:
+                ya = runner.forward(x)
+                yb = runner.forward(x, collective="reduce_scatter")
+                tol = 1e-4 * float(yb.abs().max()) + 1e-6 if dtype == torch.float32 else 2e-2 * float(yb.abs().max()) + 1e-3
+                ok = int(float((ya - yb).abs().max()) <= tol)
+                del ya, yb
+            except Exception as exc:                      # noqa: BLE001 -- any failure means "do not use it"
+                print(f"[bench] rank {rank}: sparse exchange failed its self-check: {exc!r}", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            if dist is not None:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                runner.collective = "reduce_scatter"
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -414,10 +436,16 @@ def main():
                    "parallelism": "single GPU" if world == 1 else (
                        f"destination-row partition x{world}, X replicated, no collective (labelled alternative)"
                        if args.partition == "dst" else
-                       f"source-edge partition x{world} + RCCL {args.collective} of the partial Y[V,d] "
-                       f"({args.blocks} stages, overlapped with the SpMM)"),
+                       f"source-edge partition x{world} + RCCL "
+                       + (f"sparse all-to-all of the partial Y[V,d]'s non-empty rows ({runner.nonempty_fraction:.2f} of them; "
+                          "same sums as the reduce-scatter, checked before timing)" if runner.collective == "sparse"
+                          else f"{runner.collective} of the partial Y[V,d]")
+                       + f" ({args.blocks} stages, overlapped with the SpMM)"),
                    "graph_build_s": t_build},
     }
+    if runner is not None:
+        out["config"]["collective"] = runner.collective
+        out["config"]["partial_rows_nonempty"] = round(runner.nonempty_fraction, 4)
     seal_sharded = None
     if not args.no_twowl:
         del y

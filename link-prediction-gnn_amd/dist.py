@@ -17,6 +17,13 @@ are therefore cut into S stages; stage s holds sub-block s of EVERY rank's shard
 [G, rows, d] so that one reduce_scatter_tensor serves it, and the collective of stage s is issued
 asynchronously while the SpMM of stage s+1 runs.
 
+Sparse exchange.  A rank's partial has a row for EVERY destination, but only the rows that receive an edge from
+its sources are non-zero (the bench's RMAT graph: 58 % of them).  Which rows those are is a property of the graph,
+known when it is built: ``collective="sparse"`` packs a stage's non-empty rows (one gather), moves them with ONE
+variable-split all-to-all, and the owner adds each peer's rows into its shard in rank order (unique row ids per
+peer: no atomics race, fixed order).  Same result as the reduce-scatter, 0.58 x the bytes on the links -- which is
+what bounds the step at 2 and 4 GPUs.  ``collective="auto"`` takes it when fewer than 3/4 of the rows are non-empty.
+
 The reference has no distributed code at all; this file has no reference counterpart.
 """
 from typing import Callable, List, Optional, Tuple
@@ -59,6 +66,8 @@ class SourcePartitionedSpMM:
     edge_index_local: [2, E_local] int64 with GLOBAL ids; every source must lie in `src_range`.
     forward(x_local [hi-lo, d]):
         collective="reduce_scatter" -> this rank's shard  Y[rank*shard : (rank+1)*shard]  (padded)
+        collective="sparse"         -> the same shard, only the non-empty rows of the partial on the wire
+        collective="auto"           -> "sparse" when fewer than 3/4 of the partial's rows are non-empty
         collective="all_reduce"     -> the full Y [V, d] on every rank
     `block_spmm` (CPU tests): callable (stage, dst_rows LongTensor, x_local) -> partial rows for
     those destination rows, replacing the HIP path.
@@ -83,21 +92,51 @@ class SourcePartitionedSpMM:
         for s in range(self.n_stages):
             base = torch.arange(self.world, device=dev).view(-1, 1) * self.shard + s * self.sub
             self.stage_rows.append((base + torch.arange(self.sub, device=dev).view(1, -1)).reshape(-1))
+        src, dst = edge_index_local[0] - lo, edge_index_local[1]
+        if edge_index_local.numel() and (int(src.min()) < 0 or int(src.max()) >= hi - lo):
+            raise ValueError("SourcePartitionedSpMM: an edge's source is outside this rank's range")
+        owner = torch.div(dst, self.shard, rounding_mode="floor")
+        within = dst - owner * self.shard
+        stage = torch.div(within, self.sub, rounding_mode="floor")
+        local = owner * self.sub + (within - stage * self.sub)          # row inside the stage buffer
         if block_spmm is None:
             from .ops import CSRGraph
-            src, dst = edge_index_local[0] - lo, edge_index_local[1]
-            if edge_index_local.numel() and (int(src.min()) < 0 or int(src.max()) >= hi - lo):
-                raise ValueError("SourcePartitionedSpMM: an edge's source is outside this rank's range")
-            owner = torch.div(dst, self.shard, rounding_mode="floor")
-            within = dst - owner * self.shard
-            stage = torch.div(within, self.sub, rounding_mode="floor")
-            local = owner * self.sub + (within - stage * self.sub)          # row inside the stage buffer
             for s in range(self.n_stages):
                 m = stage == s
                 ei = torch.stack([src[m], local[m]])
                 w = None if edge_weight is None else edge_weight[m]
                 self.graphs.append(CSRGraph.from_edge_index(ei, self.world * self.sub, hi - lo, edge_weight=w))
+        self._plan_sparse(stage, local, dev, ready)
         self._stage_buf = {}
+
+    def _plan_sparse(self, stage, local, dev, ready):
+        """which rows of every stage buffer are non-empty on every rank (one all_gather of a byte mask at build time),
+        and from that the gather list, the split sizes and the receive-side row ids of the sparse exchange."""
+        import torch.distributed as dist
+        rows = self.world * self.sub
+        mask = torch.zeros((self.n_stages, rows), dtype=torch.uint8, device=dev)
+        if stage.numel():
+            mask.view(-1)[stage * rows + local] = 1
+        if ready and self.world > 1:
+            every = [torch.empty_like(mask) for _ in range(self.world)]
+            dist.all_gather(every, mask, group=self.group)
+            every = torch.stack(every)                                    # [world, S, world * sub]
+        else:
+            every = mask[None]
+        every = every.view(self.world, self.n_stages, self.world, self.sub)
+        self.nonempty_fraction = float(every.float().mean())
+        use = self.collective == "sparse" or (self.collective == "auto" and self.nonempty_fraction <= 0.75)
+        if self.collective == "auto":
+            self.collective = "sparse" if use else "reduce_scatter"
+        if not use:
+            return
+        mine = every[self.rank]                                           # [S, world(owner), sub]
+        self.send_idx = [torch.nonzero(mine[s].reshape(-1)).flatten() for s in range(self.n_stages)]
+        self.in_splits = [mine[s].sum(1, dtype=torch.int64).tolist() for s in range(self.n_stages)]
+        to_me = every[:, :, self.rank]                                    # [world(peer), S, sub]
+        self.recv_idx = [[torch.nonzero(to_me[p, s]).flatten() for p in range(self.world)] for s in range(self.n_stages)]
+        self.out_splits = [[int(ix.numel()) for ix in self.recv_idx[s]] for s in range(self.n_stages)]
+        self.max_split = every.sum(-1, dtype=torch.int64).amax(dim=(0, 2)).tolist()    # per stage, the same on every rank
 
     def nnz(self):
         return sum(g.nnz() for g in self.graphs)
@@ -109,7 +148,9 @@ class SourcePartitionedSpMM:
                                     for _ in range(min(self.n_stages, 3))]      # ring of staging buffers
         return self._stage_buf[key]
 
-    def forward(self, x_local, out=None):
+    def forward(self, x_local, out=None, collective=None):
+        """collective: override of the constructor's choice for this call (bench.py checks the sparse exchange against
+        the reduce-scatter once, on the same runner)."""
         import torch.distributed as dist
         d = x_local.shape[1]
         dev, dt = x_local.device, x_local.dtype
@@ -117,7 +158,12 @@ class SourcePartitionedSpMM:
         backend = dist.get_backend(self.group) if use_dist else None
         asyn = use_dist and backend != "gloo"
         bufs = self._buffers(d, dt, dev)
-        rs = self.collective == "reduce_scatter"
+        mode = collective or self.collective
+        if mode == "sparse" and (not hasattr(self, "send_idx") or (x_local.is_cuda and dt != torch.float32)):
+            mode = "reduce_scatter"           # no plan (dense graph) or bf16 storage: the dense collective
+        if mode == "sparse":
+            return self._forward_sparse(x_local, out, bufs, use_dist, asyn)
+        rs = mode == "reduce_scatter"
         if rs:
             y = out if out is not None else torch.empty((self.shard, d), dtype=dt, device=dev)
         else:       # padded row space [world, n_stages, sub, d]; the caller gets the first n_nodes rows
@@ -164,6 +210,85 @@ class SourcePartitionedSpMM:
             out.copy_(full[: self.n_nodes])
             return out
         return full[: self.n_nodes]
+
+
+    # ---- sparse exchange ------------------------------------------------------------------------------------
+    def _gather_rows(self, buf, idx):
+        if buf.is_cuda:
+            from . import ops
+            return ops.embedding(buf, idx)                            # lpg_embedding_f32: out[i, :] = buf[idx[i], :]
+        return buf[idx]
+
+    def _add_rows(self, y_stage, idx, rows):
+        if not idx.numel():
+            return
+        if y_stage.is_cuda:
+            from . import ops
+            ops.scatter_add_rows(rows, idx, y_stage)                  # unique ids per peer: one add per element
+        else:
+            y_stage.index_add_(0, idx, rows)
+
+    def _exchange(self, send, s, use_dist, asyn):
+        """all-to-all of the packed rows of stage s; returns (recv [sum(out_splits), d], work or None)."""
+        import torch.distributed as dist
+        d = send.shape[1]
+        recv = torch.empty((sum(self.out_splits[s]), d), dtype=send.dtype, device=send.device)
+        if not use_dist:
+            recv.copy_(send)
+            return recv, None
+        if asyn:
+            work = dist.all_to_all_single(recv, send, self.out_splits[s], self.in_splits[s], group=self.group, async_op=True)
+            return recv, work
+        # gloo (CPU tests) has no all_to_all: every rank publishes its padded per-owner pieces, takes its own
+        width = max(int(self.max_split[s]), 1)                  # a width every rank agrees on
+        pad = send.new_zeros((self.world, width, d))
+        o = 0
+        for r, c in enumerate(self.in_splits[s]):
+            pad[r, :c] = send[o:o + c]
+            o += c
+        every = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(every, pad, group=self.group)
+        o = 0
+        for p, c in enumerate(self.out_splits[s]):
+            recv[o:o + c] = every[p][self.rank, :c]
+            o += c
+        return recv, None
+
+    def _forward_sparse(self, x_local, out, bufs, use_dist, asyn):
+        d = x_local.shape[1]
+        dev, dt = x_local.device, x_local.dtype
+        y = out if out is not None else torch.empty((self.shard, d), dtype=dt, device=dev)
+        y.zero_()
+        pending = [None] * len(bufs)          # (work, stage, recv, send): recv lands in y once the work is done
+
+        def retire(slot):
+            if pending[slot] is None:
+                return
+            work, st, recv, _send = pending[slot]
+            if work is not None:
+                work.wait()
+            ys = y[st * self.sub:(st + 1) * self.sub]
+            o = 0
+            for p in range(self.world):                               # fixed order: rank 0's rows first
+                c = self.out_splits[st][p]
+                self._add_rows(ys, self.recv_idx[st][p], recv[o:o + c])
+                o += c
+            pending[slot] = None
+
+        for s in range(self.n_stages):
+            slot = s % len(bufs)
+            retire(slot)
+            buf = bufs[slot]
+            if self.block_spmm is not None:
+                buf.copy_(self.block_spmm(s, self.stage_rows[s], x_local))
+            else:
+                self.graphs[s].spmm(x_local, out=buf)
+            send = self._gather_rows(buf, self.send_idx[s])           # the non-empty rows, grouped by owner
+            recv, work = self._exchange(send, s, use_dist, asyn)      # overlaps the SpMM of stage s+1
+            pending[slot] = (work, s, recv, send)
+        for slot in range(len(bufs)):
+            retire(slot)
+        return y
 
 
 class ShardedLinkScorer:

@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
     from lpgnn_amd import dist as ldist
     from oracle import aggregation as agg
     rng = np.random.default_rng(0)                      # identical on every rank
-    n, e, d = 203, 5000, 12
+    n, e, d = 203, int(os.environ.get("LPG_TEST_EDGES", "5000")), 12
     ei = rng.integers(0, n, size=(2, e)).astype(np.int64)
     x = rng.standard_normal((n, d))
     lo, hi = ldist.source_range(n, world, rank)
@@ -49,11 +49,20 @@ def _worker(rank, world, port, q):
     rowptr, col, _, _ = agg.coo_to_csr(ei[1], ei[0], n)
     want = agg.csr_spmm(rowptr, col, None, x)
     errs = []
-    for collective in ("reduce_scatter", "all_reduce"):
+    for collective in ("reduce_scatter", "all_reduce", "sparse", "auto"):
         op = ldist.SourcePartitionedSpMM(torch.from_numpy(mine), n, (lo, hi), n_blocks=5, block_spmm=block_spmm,
                                          collective=collective)
         y = op.forward(torch.from_numpy(x[lo:hi])).numpy()
-        if collective == "reduce_scatter":       # this rank's (padded) shard of the destination rows
+        if collective in ("sparse", "auto"):
+            assert 0.0 < op.nonempty_fraction <= 1.0
+            assert op.collective == ("sparse" if collective == "sparse" or op.nonempty_fraction <= 0.75 else "reduce_scatter")
+            if e <= 150:
+                assert op.collective == "sparse" and op.nonempty_fraction < 0.5
+            if op.collective == "sparse":        # on the wire: exactly the destination rows this rank's edges reach
+                assert sum(sum(sp) for sp in op.in_splits) == np.unique(mine[1]).size
+            y2 = op.forward(torch.from_numpy(x[lo:hi]), collective="reduce_scatter").numpy()
+            assert np.abs(y - y2).max() < 1e-12
+        if collective != "all_reduce":           # this rank's (padded) shard of the destination rows
             r0 = rank * op.shard
             ref = np.zeros((op.shard, d))
             ref[: max(0, min(n, r0 + op.shard) - r0)] = want[r0:r0 + op.shard]
@@ -62,6 +71,24 @@ def _worker(rank, world, port, q):
             errs.append(float(np.abs(y - want).max()))
     q.put((rank, max(errs), mine.shape[1]))
     dist.destroy_process_group()
+
+
+def test_source_partition_sparse_graph_world2(monkeypatch):
+    """few edges: most rows of a partial are empty, `auto` must pick the sparse exchange and agree with the dense one."""
+    monkeypatch.setenv("LPG_TEST_EDGES", "150")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(r[2] for r in res) == 150
+    for _, err, _ in res:
+        assert err < 1e-12
 
 
 def test_source_partition_allreduce_world2():
