@@ -121,6 +121,14 @@ class SourcePartitionedSpMM:
             every = [torch.empty_like(mask) for _ in range(self.world)]
             dist.all_gather(every, mask, group=self.group)
             every = torch.stack(every)                                    # [world, S, world * sub]
+        elif self.world > 1:
+            # ranks emulated without a process group (layout tests): the peers' masks are unknown, no sparse plan
+            self.nonempty_fraction = float(mask.float().mean())
+            if self.collective == "sparse":
+                raise ValueError("SourcePartitionedSpMM: collective='sparse' needs an initialised process group")
+            if self.collective == "auto":
+                self.collective = "reduce_scatter"
+            return
         else:
             every = mask[None]
         every = every.view(self.world, self.n_stages, self.world, self.sub)
