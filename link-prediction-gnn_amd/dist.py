@@ -107,6 +107,17 @@ class SourcePartitionedSpMM:
                 w = None if edge_weight is None else edge_weight[m]
                 self.graphs.append(CSRGraph.from_edge_index(ei, self.world * self.sub, hi - lo, edge_weight=w))
         self._plan_sparse(stage, local, dev, ready)
+        self.graphs_packed = []
+        if block_spmm is None and self.collective == "sparse":
+            # the sparse exchange's SpMM writes the PACKED send buffer directly: destination rows renumbered to their
+            # position among the stage's non-empty rows (owner-major), so nothing is gathered and no empty row exists
+            from .ops import CSRGraph
+            for s in range(self.n_stages):
+                m = stage == s
+                remap = torch.cumsum(self.row_mask[s].to(torch.int64), 0) - 1
+                ei = torch.stack([src[m], remap[local[m]]])
+                w = None if edge_weight is None else edge_weight[m]
+                self.graphs_packed.append(CSRGraph.from_edge_index(ei, int(self.send_idx[s].numel()), hi - lo, edge_weight=w))
         self._stage_buf = {}
 
     def _plan_sparse(self, stage, local, dev, ready):
@@ -139,6 +150,7 @@ class SourcePartitionedSpMM:
         if not use:
             return
         mine = every[self.rank]                                           # [S, world(owner), sub]
+        self.row_mask = mine.reshape(self.n_stages, -1)                   # own non-empty rows per stage buffer
         self.send_idx = [torch.nonzero(mine[s].reshape(-1)).flatten() for s in range(self.n_stages)]
         self.in_splits = [mine[s].sum(1, dtype=torch.int64).tolist() for s in range(self.n_stages)]
         to_me = every[:, :, self.rank]                                    # [world(peer), S, sub]
@@ -287,11 +299,14 @@ class SourcePartitionedSpMM:
             slot = s % len(bufs)
             retire(slot)
             buf = bufs[slot]
-            if self.block_spmm is not None:
+            if self.graphs_packed:
+                send = self.graphs_packed[s].spmm(x_local)            # straight into the packed rows (owner-major)
+            elif self.block_spmm is not None:
                 buf.copy_(self.block_spmm(s, self.stage_rows[s], x_local))
+                send = self._gather_rows(buf, self.send_idx[s])       # the non-empty rows, grouped by owner
             else:
-                self.graphs[s].spmm(x_local, out=buf)
-            send = self._gather_rows(buf, self.send_idx[s])           # the non-empty rows, grouped by owner
+                self.graphs[s].spmm(x_local, out=buf, skip_empty_rows=True)    # empty rows are never gathered
+                send = self._gather_rows(buf, self.send_idx[s])
             recv, work = self._exchange(send, s, use_dist, asyn)      # overlaps the SpMM of stage s+1
             pending[slot] = (work, s, recv, send)
         for slot in range(len(bufs)):

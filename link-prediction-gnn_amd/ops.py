@@ -215,8 +215,10 @@ class CSRGraph:
             self._ws["spmm"] = ws
         return ws, nbytes
 
-    def spmm(self, x, row_scale=None, bias=None, act=None, out=None, use_val=True):
-        """Y = act(row_scale * (A @ x) + bias);  x [n_cols, d] float32 or bfloat16."""
+    def spmm(self, x, row_scale=None, bias=None, act=None, out=None, use_val=True, skip_empty_rows=False):
+        """Y = act(row_scale * (A @ x) + bias);  x [n_cols, d] float32 or bfloat16.
+        skip_empty_rows: rows without edges are left UNWRITTEN (the caller never reads them: the sparse multi-GPU
+        exchange gathers only the non-empty rows of a partial)."""
         lib = _lib.load()
         _need_gpu(x, row_scale, bias)
         if x.dim() != 2 or x.shape[0] != self.n_cols:
@@ -233,7 +235,8 @@ class CSRGraph:
         val = self.val if use_val else None
         ws, nbytes = self._workspace(d)
         args = (_ptr(self._plan), _ptr(self.rowptr), _ptr(self.col), _ptr(val), _ptr(x), x.stride(0), _ptr(out),
-                out.stride(0), self.n_rows, self.n_cols, self.e_cap, d, _ptr(row_scale), _ptr(bias), ACT[act], self.n_empty,
+                out.stride(0), self.n_rows, self.n_cols, self.e_cap, d, _ptr(row_scale), _ptr(bias), ACT[act],
+                0 if skip_empty_rows else self.n_empty,
                 self.max_row, _ptr(ws), nbytes, _stream())
         if x.dtype == torch.float32:
             _lib.check(lib.lpg_csr_spmm_f32(*args), "csr_spmm_f32")
