@@ -330,6 +330,8 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
+    if os.environ.get("LPG_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = 0                                              # rehearsal: every rank on the one GPU of the box
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import lpgnn_amd
@@ -337,7 +339,11 @@ def main():
     dist = None
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("LPG_BENCH_BACKEND", "nccl")         # "gloo": rehearsal of the N > 1 logic on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     elt = 4 if args.dtype == "f32" else 2
