@@ -450,6 +450,16 @@ def main():
                    "graph_build_s": t_build},
     }
     if runner is not None:
+        # the step's local SpMM work alone (no exchange), so that compute, exchange and overlap can be told apart
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        runner.compute_only(x)
+        e0.record()
+        for _ in range(5):
+            runner.compute_only(x)
+        e1.record()
+        torch.cuda.synchronize()
+        out["config"]["rank0_spmm_only_ms_per_step"] = e0.elapsed_time(e1) / 5
         out["config"]["collective"] = runner.collective
         out["config"]["partial_rows_nonempty"] = round(runner.nonempty_fraction, 4)
     seal_sharded = None

@@ -232,6 +232,15 @@ class SourcePartitionedSpMM:
         return full[: self.n_nodes]
 
 
+    def compute_only(self, x_local):
+        """the stage SpMMs of one step without any exchange (bench.py reports it next to the whole step)."""
+        bufs = self._buffers(x_local.shape[1], x_local.dtype, x_local.device)
+        for s in range(self.n_stages):
+            if self.collective == "sparse" and self.graphs_packed:
+                self.graphs_packed[s].spmm(x_local)
+            elif self.block_spmm is None:
+                self.graphs[s].spmm(x_local, out=bufs[s % len(bufs)])
+
     # ---- sparse exchange ------------------------------------------------------------------------------------
     def _gather_rows(self, buf, idx):
         if buf.is_cuda:
