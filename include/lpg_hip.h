@@ -57,6 +57,10 @@ int lpg_scatter_add_i64(const int64_t* src, const int64_t* index, int64_t E, int
                         int64_t* out, int64_t N, int32_t* err_flag, void* stream);
 int lpg_scatter_add_f32(const float* src, const int64_t* index, int64_t E, int64_t d,
                         float* out, int64_t N, int32_t* err_flag, void* stream);
+/* out[index[e], :] += src[e, :] for DISTINCT index entries (a caller contract: the rows one peer contributes to
+ * a shard in the sparse multi-GPU exchange, lpgnn_amd/dist.py): plain 16-byte read-modify-writes, no atomics. */
+int lpg_rows_add_f32(const float* src, const int64_t* index, int64_t E, int64_t d, float* out,
+                     int64_t N, int32_t* err_flag, void* stream);
 
 /* In-degree histogram, the reference's only direct torch_scatter call:
  * degree(ei, num_node) = scatter_add(ones_like(ei[1]), ei[1], dim_size=N)  [TwoWL/utils.py:8-10].

@@ -123,7 +123,49 @@ __global__ __launch_bounds__(kBlock) void scatter_add_f32_kernel(const float* __
       flag_error(err_flag, LPG_F_INDEX_RANGE);
   }
 }
+
+// out[index[e], :] += src[e, :] for DISTINCT index entries (the rows one peer contributes to a shard in the sparse
+// multi-GPU exchange): no two threads touch the same element, so plain 16-byte read-modify-writes replace the
+// memory-side float atomics (which run at ~1.3 TB/s).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void rows_add_f32_kernel(const float* __restrict__ src,
+                                                              const int64_t* __restrict__ index, int64_t E, int64_t d,
+                                                              float* __restrict__ out, int64_t N, int32_t* err_flag) {
+  const int64_t dv = d / VEC, total = E * dv;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t e = t / dv, c = (t - e * dv) * VEC;
+    const int64_t j = index[e];
+    if (j < 0 || j >= N) {
+      flag_error(err_flag, LPG_F_INDEX_RANGE);
+      continue;
+    }
+    if constexpr (VEC == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(src + e * d + c);
+      float4* o = reinterpret_cast<float4*>(out + j * d + c);
+      const float4 b = *o;
+      *o = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    } else {
+      out[j * d + c] += src[e * d + c];
+    }
+  }
+}
 }  // namespace
+
+LPG_EXPORT int lpg_rows_add_f32(const float* src, const int64_t* index, int64_t E, int64_t d, float* out, int64_t N,
+                                int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(E >= 0 && N >= 0 && d >= 1, "rows_add_f32: bad sizes");
+  if (E == 0) return LPG_OK;
+  LPG_REQUIRE(src && index && out, "rows_add_f32: null pointer");
+  const bool wide = d % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  if (wide)
+    hipLaunchKernelGGL(rows_add_f32_kernel<4>, dim3(grid_for(E * d / 4)), dim3(kBlock), 0, as_stream(stream), src, index, E,
+                       d, out, N, err_flag);
+  else
+    hipLaunchKernelGGL(rows_add_f32_kernel<1>, dim3(grid_for(E * d)), dim3(kBlock), 0, as_stream(stream), src, index, E, d,
+                       out, N, err_flag);
+  return check_launch("rows_add_f32");
+}
 
 LPG_EXPORT int lpg_scatter_add_i64(const int64_t* src, const int64_t* index, int64_t E, int64_t d, int64_t* out,
                                    int64_t N, int32_t* err_flag, void* stream) {

@@ -253,7 +253,7 @@ class SourcePartitionedSpMM:
             return
         if y_stage.is_cuda:
             from . import ops
-            ops.scatter_add_rows(rows, idx, y_stage)                  # unique ids per peer: one add per element
+            ops.rows_add_distinct(rows, idx, y_stage)                 # unique ids per peer: plain read-modify-writes
         else:
             y_stage.index_add_(0, idx, rows)
 

@@ -87,6 +87,20 @@ def scatter_add_rows(src: Optional[torch.Tensor], index: torch.Tensor, out: torc
     return out
 
 
+def rows_add_distinct(src: torch.Tensor, index: torch.Tensor, out: torch.Tensor):
+    """out[index[e], :] += src[e, :] where the entries of `index` are DISTINCT (no atomics); float32 [N, d]."""
+    lib = _lib.load()
+    _need_gpu(index, out, src)
+    index = _c(index, torch.int64)
+    src = _c(src, torch.float32)
+    assert out.is_contiguous() and out.dtype == torch.float32
+    N = out.shape[0]
+    d = out.numel() // N if N > 0 else 1
+    _lib.check(lib.lpg_rows_add_f32(_ptr(src), _ptr(index), index.numel(), d, _ptr(out), N, _ptr(err_flag(out.device)),
+                                    _stream()), "rows_add_f32")
+    return out
+
+
 def degree(index: torch.Tensor, n: int) -> torch.Tensor:
     """int64 histogram of `index` over [0, n): the reference's degree() (TwoWL/utils.py:8-10) without
     materialising the ones vector; big lists are counted by sorting (no atomics)."""

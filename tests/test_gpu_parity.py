@@ -48,6 +48,26 @@ def test_degree_bit_exact(dev):
         assert got.dtype == torch.int64 and np.array_equal(_np(got), twowl_int.degree(ei, n))
 
 
+def test_rows_add_distinct(dev):
+    """lpg_rows_add_f32 (the unpack of the sparse multi-GPU exchange): out[index[e]] += src[e] for distinct indices,
+    bit-equal to index_add_ (one add per element), any row width, out-of-range indices skipped and flagged."""
+    from lpgnn_amd import ops
+    rng = np.random.default_rng(3)
+    for n, e, d in [(1000, 400, 128), (50, 50, 7), (5, 0, 4), (200_000, 120_000, 128)]:
+        idx = torch.from_numpy(rng.permutation(n)[:e].astype(np.int64)).to(dev)
+        src = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32)).to(dev)
+        out = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(dev)
+        want = out.clone().index_add_(0, idx, src)
+        got = ops.rows_add_distinct(src, idx, out.clone())
+        assert torch.equal(got, want)
+    bad = torch.tensor([0, 7, 1000], device=dev)
+    o = torch.zeros((1000, 4), device=dev)
+    ops.rows_add_distinct(torch.ones((3, 4), device=dev), bad, o)
+    with pytest.raises(IndexError):
+        ops.raise_if_flagged(torch.device(dev))
+    assert float(o.sum()) == 8.0
+
+
 def test_degree_sorted_path_bit_exact(dev):
     """E >= 4 M takes the sort-and-count path (csrc/degree.hip): equal to numpy's bincount and to the atomic
     kernels, including odd lengths, a hub destination, empty nodes and out-of-range indices (skipped + flagged)."""
