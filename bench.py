@@ -349,6 +349,7 @@ def main():
     elt = 4 if args.dtype == "f32" else 2
     N, E, d = args.nodes, args.edges, args.dim
 
+    exchange_trial_ms = None
     t_build = time.time()
     force_dist = os.environ.get("LPG_BENCH_FORCE_DIST") == "1"     # rehearse the N > 1 code path on one GPU
     if world > 1 and args.partition == "dst":
@@ -396,6 +397,25 @@ def main():
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 runner.collective = "reduce_scatter"
+            elif args.collective == "auto":
+                # both forms give the same sums: keep the one that is faster HERE (max over ranks of 3 untimed steps each);
+                # how well RCCL drives the links with a ring reduce-scatter vs a direct all-to-all is a property of the node
+                tried = {}
+                for mode in ("sparse", "reduce_scatter"):
+                    runner.forward(x, collective=mode)
+                    torch.cuda.synchronize()
+                    if dist is not None:
+                        dist.barrier()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        runner.forward(x, collective=mode)
+                    torch.cuda.synchronize()
+                    tm = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+                    if dist is not None:
+                        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                    tried[mode] = float(tm.item()) / 3 * 1e3
+                runner.collective = min(tried, key=tried.get)
+                exchange_trial_ms = tried
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -461,6 +481,8 @@ def main():
         torch.cuda.synchronize()
         out["config"]["rank0_spmm_only_ms_per_step"] = e0.elapsed_time(e1) / 5
         out["config"]["collective"] = runner.collective
+        if exchange_trial_ms is not None:
+            out["config"]["exchange_trial_ms_per_step"] = exchange_trial_ms
         out["config"]["partial_rows_nonempty"] = round(runner.nonempty_fraction, 4)
     seal_sharded = None
     if not args.no_twowl:
