@@ -185,6 +185,60 @@ def test_bench_combines_secondary_figure_through_the_store_world2():
     assert "error" in bad0 and bad0["ranks_failed"] == 1
 
 
+def _gpu_worker(rank, world, port, q):
+    """two real ranks on ONE GPU (gloo as the transport, HIP kernels for everything else): the packed-row SpMM, the
+    sparse exchange's plan and lpg_rows_add_f32 under a real source partition, against the unpartitioned SpMM."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lpgnn_amd
+    from lpgnn_amd import dist as ldist
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(7)               # identical on every rank
+    n, e, d = 30_011, 90_000, 32
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei[1, : e // 2] = torch.randint(0, n // 50, (e // 2,), generator=gen)      # many rows receive nothing
+    x = torch.randn((n, d), generator=gen)
+    lo, hi = ldist.source_range(n, world, rank)
+    mine = ldist.partition_edges_by_source(ei, n, world, rank).to(dev)
+    full = lpgnn_amd.CSRGraph.from_edge_index(ei.to(dev), n, n).spmm(x.to(dev))
+    out = {}
+    for collective in ("sparse", "reduce_scatter"):
+        op = ldist.SourcePartitionedSpMM(mine, n, (lo, hi), n_blocks=3, collective=collective)
+        y = op.forward(x[lo:hi].to(dev))
+        r0 = rank * op.shard
+        ref = torch.zeros((op.shard, d), device=dev)
+        ref[: max(0, min(n, r0 + op.shard) - r0)] = full[r0:r0 + op.shard]
+        out[collective] = (float((y - ref).abs().max()), float(ref.abs().max()), op.nonempty_fraction, bool(op.graphs_packed))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_exchange_two_ranks_on_the_gpu():
+    import pytest
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        for collective in ("sparse", "reduce_scatter"):
+            err, scale, frac, packed = res[rank][collective]
+            assert err <= 1e-5 * (scale + 1.0), (rank, collective, err)
+            assert frac < 0.75 and packed == (collective == "sparse")
+
+
+test_sparse_exchange_two_ranks_on_the_gpu = __import__("pytest").mark.gpu(test_sparse_exchange_two_ranks_on_the_gpu)
+
+
 def test_ranges_cover_and_balance():
     from lpgnn_amd import dist as ldist
     for n, w in [(10, 3), (5_000_000, 8), (7, 8), (1, 1)]:
