@@ -68,3 +68,38 @@ def test_train_csr_is_symmetric_sorted_unique():
         adj[u, v] = adj[v, u] = True
     for r in range(50):
         assert cl[rp[r]:rp[r + 1]].tolist() == np.nonzero(adj[r])[0].tolist()
+
+
+def test_three_way_bf16_split_is_exact():
+    """the split the SEAL conv kernel applies to H (csrc/seal_conv.hip, split3): hi = top 16 bits of v, mid = top 16
+    bits of (v - hi), lo = (v - hi - mid) truncated to 16 bits -- restated in numpy: every term is a bf16 value and
+    hi + mid + lo == v EXACTLY, so sum_k a_k * v_k with small-integer a_k (the 0 / 1 / 2 adjacency entries) is the
+    sum of three exact bf16 products per term.  (Exact while the third term stays a NORMAL bf16 number: |v| >= 2^-110;
+    below that the loss is under 2^-133 absolute -- the last two asserts pin that too.)"""
+    rng = np.random.default_rng(0)
+    v = np.concatenate([rng.standard_normal(200_000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 200_000),
+                        np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -110, 65504.0, 1e38, -3e-33], dtype=np.float32)])
+    v = v.astype(np.float32)
+    tiny = v[(np.abs(v) < 2.0 ** -110) & (v != 0)]
+    v = v[(np.abs(v) >= 2.0 ** -110) | (v == 0)]
+
+    def top16(x):
+        return (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+
+    hi = top16(v)
+    r1 = (v - hi).astype(np.float32)
+    mid = top16(r1)
+    r2 = (r1 - mid).astype(np.float32)
+    lo = top16(r2)
+    assert np.array_equal(lo, r2)                                    # nothing is lost in the third term
+    back = (hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64))
+    assert np.array_equal(back, v.astype(np.float64))                # exact, not just close
+    th = top16(tiny)
+    tr1 = (tiny - th).astype(np.float32)
+    tm = top16(tr1)
+    tl = top16((tr1 - tm).astype(np.float32))
+    assert np.abs(th.astype(np.float64) + tm + tl - tiny).max(initial=0.0) < 2.0 ** -133
+    for a in (1.0, 2.0):                                             # products with the adjacency's 1 / 2 are exact too
+        for t in (hi, mid, lo):
+            p = (np.float32(a) * t).astype(np.float32)
+            assert np.array_equal(p.astype(np.float64), a * t.astype(np.float64))
