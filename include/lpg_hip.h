@@ -251,6 +251,16 @@ int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8
                          int64_t* out, void* workspace, int64_t workspace_bytes,
                          int64_t* count_host, void* stream);
 
+/* The train-positive graph `A` / `G` of SEAL (SEAL/config/subgraph.py:27-31,70-72) for SMALL graphs
+ * (n_nodes <= lpg_seal_train_csr_small_max_nodes() = 8192; fb-pages-food has 620): symmetric, neighbours ascending
+ * and unique per row, self loops kept.  pairs [n_pairs, 2] int64 (the train positives); `bits` = scratch of
+ * n_nodes * ceil(n_nodes / 32) * 4 bytes (zeroed by the call); rowptr [n_nodes + 1]; col capacity col_cap >=
+ * 2 * n_pairs.  Three launches, no host sync (rowptr[n_nodes] = nnz stays on the device). */
+int64_t lpg_seal_train_csr_small_max_nodes(void);
+int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, void* bits,
+                             int64_t bits_bytes, int64_t* rowptr, int32_t* col, int64_t col_cap,
+                             int32_t* err_flag, void* stream);
+
 /* ---------------------------------------------------------------- SEAL structure path (a10-a12)
  * Batched 0/1-hop enclosing subgraphs + DRNL labels on the train graph given as a symmetric CSR
  * (adj_rowptr[n+1], adj_col sorted ascending per row, self loops allowed)

@@ -67,6 +67,20 @@ def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
     positive = torch.as_tensor(np.asarray(positive), dtype=torch.int64, device=device)
     test_size = int(len(positive) * test_ratio)
     train_pos = positive[: len(positive) - test_size] if test_size > 0 else positive
+    if positive.is_cuda and n_nodes <= 8192:
+        # small graphs (the reference's own: 620 nodes): a bit matrix and three launches, no host sync
+        lib = _lib.load()
+        train_pos = train_pos.contiguous()
+        P = train_pos.shape[0]
+        words = (n_nodes + 31) // 32
+        bits = torch.empty(n_nodes * words, dtype=torch.int32, device=positive.device)
+        rowptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=positive.device)
+        col = torch.empty(max(2 * P, 1), dtype=torch.int32, device=positive.device)
+        _lib.check(lib.lpg_seal_train_csr_small(_ops._ptr(train_pos), P, n_nodes, _ops._ptr(bits), bits.numel() * 4,
+                                                _ops._ptr(rowptr), _ops._ptr(col), col.numel(),
+                                                _ops._ptr(_ops.err_flag(positive.device)), _ops._stream()),
+                   "seal_train_csr_small")
+        return TrainGraph(rowptr, col, n_nodes)      # (col's tail past rowptr[n] is unused capacity; hub matrix: n too small)
     u, v = train_pos[:, 0], train_pos[:, 1]
     keys = torch.unique(torch.cat([u * n_nodes + v, v * n_nodes + u]))       # sorted, deduplicated
     rows = torch.div(keys, n_nodes, rounding_mode="floor")
@@ -199,12 +213,13 @@ def auto_hop(positive, negative, graph, test_ratio=0.1):
     y = torch.cat([torch.ones(test_size, device=dev), torch.zeros(test_size, device=dev)])
     n = graph.n_nodes
     deg = (graph.rowptr[1:] - graph.rowptr[:-1])
-    keys = torch.repeat_interleave(torch.arange(n, device=dev), deg) * n + graph.col.long()    # sorted (row, col) keys
+    col = graph.col[: int(graph.rowptr[-1])].long()                  # (the col buffer may have spare capacity)
+    keys = torch.repeat_interleave(torch.arange(n, device=dev), deg) * n + col    # sorted (row, col) keys
     u, v = pairs[:, 0], pairs[:, 1]
     du = deg[u]
     pid = torch.repeat_interleave(torch.arange(pairs.shape[0], device=dev), du)
     off = torch.arange(int(du.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(du, 0) - du, du)
-    w = graph.col.long()[graph.rowptr[u][pid] + off]                  # every neighbour w of u, per pair
+    w = col[graph.rowptr[u][pid] + off]                               # every neighbour w of u, per pair
     probe = w * n + v[pid]
     pos = torch.searchsorted(keys, probe).clamp(max=keys.numel() - 1)
     hit = keys[pos] == probe                                          # A[w, v] == 1
@@ -267,15 +282,15 @@ def compact_tag_map(batch):
     # tag on <= 128 vertices is at most 1 + 127 + 127 * 127; slot 0 takes the -1 padding
     dev = batch.tags.device
     if batch.tag_present is not None:                        # filled by the extraction kernel as it wrote the tags
-        uniq = torch.nonzero(batch.tag_present).flatten()    # ascending tags (one host sync, as before)
+        present = batch.tag_present
     else:
         present = torch.zeros(_TAG_BOUND + 2, dtype=torch.uint8, device=dev)
         present[batch.tags.reshape(-1).long() + 1] = 1
-        uniq = torch.nonzero(present[1:]).flatten()
-    T = int(uniq.numel())
-    tag_map = torch.full((int(uniq.max().item()) + 1 if T else 1,), -1, dtype=torch.int32, device=batch.tags.device)
-    tag_map[uniq.long()] = torch.arange(T, dtype=torch.int32, device=batch.tags.device)
-    return tag_map, T
+        present = present[1:]
+    # ascending tags -> 0..T-1 is an exclusive scan of the presence table; ONE host read (T), no nonzero / max round trips
+    rank = torch.cumsum(present, 0, dtype=torch.int32)
+    tag_map = torch.where(present != 0, rank - 1, torch.full_like(rank, -1))
+    return tag_map, int(rank[-1].item())
 
 
 def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.float32, build_csr=True):

@@ -1321,3 +1321,27 @@ def test_zero_size_inputs_everywhere(dev):
     graph = seal.build_train_csr(np.array([[0, 1], [1, 2]]), 3, test_ratio=0.0, device=dev)
     b = seal.extract_subgraphs(np.zeros((0, 2), dtype=np.int64), graph, 1)
     assert b.B == 0 and b.n.numel() == 0
+
+
+def test_seal_train_csr_small_matches_sort_route(dev, sl):
+    """lpg_seal_train_csr_small (bit matrix, three launches) against the sort / unique route and against numpy, on
+    fb-pages-food's train positives and on random pair lists with duplicates, self loops, reversed pairs, empty rows."""
+    from lpgnn_amd import seal
+    rng = np.random.default_rng(4)
+    cases = [(sl["positive"].astype(np.int64), 620, 0.1)]
+    for n, p in [(1, 3), (33, 500), (700, 50), (8192, 30_000), (100, 0)]:
+        cases.append((rng.integers(0, n, size=(p, 2)).astype(np.int64), n, 0.0))
+    for pos, n, ratio in cases:
+        g = seal.build_train_csr(pos, n, test_ratio=ratio, device=dev)
+        train = pos[: len(pos) - int(len(pos) * ratio)]
+        adj = np.zeros((n, n), dtype=bool)
+        if len(train):
+            adj[train[:, 0], train[:, 1]] = True
+            adj[train[:, 1], train[:, 0]] = True
+        rp, cl = _np(g.rowptr), _np(g.col)
+        assert rp[0] == 0 and rp[-1] == adj.sum() and np.array_equal(np.diff(rp), adj.sum(1))
+        assert np.array_equal(cl[: rp[-1]], np.nonzero(adj)[1])          # ascending and unique inside every row
+    with pytest.raises(IndexError):
+        seal.build_train_csr(np.array([[0, 5]]), 5, 0.0, device=dev)
+        from lpgnn_amd import ops
+        ops.raise_if_flagged(torch.device(dev))
