@@ -329,6 +329,10 @@ int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_off, const 
  * linear on the concat) the kernel also writes head_a16 [total,16] = [Z_1|Z_2|Z_3] @ head_k1; cat may then be NULL
  * (the 96-wide concat is never written).  The aggregation runs on the bf16 matrix cores through an exact three-way
  * bf16 split of H (0/1/2 adjacency entries are exact in bf16); LPG_SEAL_CONV_FP32=1 keeps the fp32 MFMA form. */
+/* first[w], w = 0 .. n_windows (n_windows + 1 entries) for lpg_seal_conv_stack_f32: one launch instead of a
+ * searchsorted / arange / clamp chain; window_rows <= 128. */
+int lpg_seal_conv_windows(const int64_t* node_off, int64_t B, int64_t n_windows, int64_t window_rows,
+                          int32_t* first, void* stream);
 int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
                             const uint32_t* adj_bits, const float* h1, int64_t ldh, const float* w2,
                             const float* w3, const float* w4, float* cat, int64_t ldc, float* key,

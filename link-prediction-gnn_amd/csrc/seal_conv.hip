@@ -484,7 +484,31 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
     __syncthreads();
   }
 }
+// first[w] = lower_bound(node_off[0..B], w * win) clamped to B: the first subgraph whose first row is >= w * win
+__global__ __launch_bounds__(kConvBlock) void seal_windows_kernel(const int64_t* __restrict__ node_off, int64_t B,
+                                                                  int64_t n_first, int64_t win, int32_t* __restrict__ first) {
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kConvBlock + threadIdx.x;
+  if (w >= n_first) return;
+  const int64_t target = w * win;
+  int64_t lo = 0, hi = B + 1;                       // node_off has B + 1 entries
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (node_off[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  first[w] = static_cast<int32_t>(lo < B ? lo : B);
+}
 }  // namespace
+
+LPG_EXPORT int lpg_seal_conv_windows(const int64_t* node_off, int64_t B, int64_t n_windows, int64_t window_rows,
+                                     int32_t* first, void* stream) {
+  LPG_REQUIRE(B >= 0 && n_windows >= 0 && window_rows >= 1 && window_rows <= WIN && B < (int64_t(1) << 31),
+              "seal_conv_windows: bad sizes (window_rows <= %d)", WIN);
+  LPG_REQUIRE(node_off && first, "seal_conv_windows: null pointer");
+  const int64_t n_first = n_windows + 1;
+  hipLaunchKernelGGL(seal_windows_kernel, dim3(static_cast<unsigned>(ceil_div(n_first, kConvBlock))), dim3(kConvBlock), 0,
+                     as_stream(stream), node_off, B, n_first, window_rows, first);
+  return check_launch("seal_conv_windows");
+}
 
 LPG_EXPORT int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
                                        const uint32_t* adj_bits, const float* h1, int64_t ldh, const float* w2,

@@ -407,8 +407,9 @@ def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None, head_k1=None):
         off = batch.node_off()
         win = int(os.environ.get("LPG_SEAL_CONV_WINDOW", "128"))    # rows per workgroup window (<= 128); A/B hook
         n_win = -(-total // win)
-        first = torch.searchsorted(off, torch.arange(n_win + 1, device=h1.device, dtype=torch.int64) * win)
-        first = first.clamp_(max=batch.B).to(torch.int32)
+        first = torch.empty(n_win + 1, dtype=torch.int32, device=h1.device)
+        _lib.check(lib.lpg_seal_conv_windows(_ops._ptr(off), batch.B, n_win, win, _ops._ptr(first), _ops._stream()),
+                   "seal_conv_windows")
         fuse = head_k1 is not None
         cat = None if fuse else torch.empty((total, 96), dtype=torch.float32, device=h1.device)
         a16 = torch.empty((total, 16), dtype=torch.float32, device=h1.device) if fuse else None
