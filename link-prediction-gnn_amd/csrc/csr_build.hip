@@ -6,9 +6,11 @@
 // The stable order inside a destination row (original edge order, appended self loop last) is
 // the order PyG's scatter-add accumulates in on CPU.
 //
-// rocPRIM's radix sort is used for the one-time sort (library primitive, not on the timed path);
-// keys are made unique -- (row << 32 | edge id) -- so the result does not depend on the
-// library's stability guarantees.
+// rocPRIM's radix sort is used for the one-time sort (library primitive, not on the timed path).
+// Small lists sort unique 64-bit keys (row << 32 | edge id).  From 2^18 entries on the sort is a STABLE
+// least-significant-digit radix sort of (row, payload) pairs over the ceil(log2 N) row bits only -- 3 passes of
+// 8 bits at |V| = 5 M instead of 7 over the 55-bit unique key -- and stability keeps the edge order inside a row;
+// without edge weights the payload is the source id itself, so the sorted payload IS `col` (no gather pass).
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -82,6 +84,114 @@ __global__ __launch_bounds__(kBlock) void coo_keys_kernel(const int64_t* __restr
       row = static_cast<uint64_t>(e - E);  // appended self loop of node e-E
     }
     keys[e] = (row << 32) | static_cast<uint64_t>(e);
+  }
+}
+
+constexpr int64_t kPairSortMin = int64_t(1) << 18;   // below: unique 64-bit keys (any sort algorithm gives the order)
+
+struct CooWs32 {
+  uint32_t* k_in;
+  uint32_t* k_out;
+  uint32_t* v_in;
+  uint32_t* v_out;
+  int32_t* loop_last;
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  int64_t total;
+};
+
+CooWs32 carve32(void* ws, int64_t E, int64_t N, int loops) {
+  CooWs32 w;
+  const int64_t M = E + (loops ? N : 0);
+  char* p = static_cast<char*>(ws);
+  uint32_t** slots[4] = {&w.k_in, &w.k_out, &w.v_in, &w.v_out};
+  for (auto slot : slots) {
+    *slot = reinterpret_cast<uint32_t*>(p);
+    p += align_up(M * 4, 256);
+  }
+  w.loop_last = reinterpret_cast<int32_t*>(p);
+  p += align_up((N + 1) * 4, 256);
+  w.sort_tmp = p;
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                  static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                  static_cast<size_t>(M > 0 ? M : 1), 0u, bits_for(N), hipStream_t(0), false);
+  w.sort_tmp_bytes = bytes;
+  w.total = (p - static_cast<char*>(ws)) + static_cast<int64_t>(align_up(bytes, 256));
+  return w;
+}
+
+// the pair form of coo_keys_kernel: key = destination row (n_rows = dropped), payload = source id (by_col) or edge id
+__global__ __launch_bounds__(kBlock) void coo_pairs_kernel(const int64_t* __restrict__ src,
+                                                           const int64_t* __restrict__ dst,
+                                                           const float* __restrict__ val, int64_t E, int64_t n_rows,
+                                                           int64_t n_cols, int loops, int flip, int by_col,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                           int32_t* __restrict__ loop_last, int32_t* err_flag) {
+  const int64_t M = E + (loops ? n_rows : 0);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < M; e += stride) {
+    uint32_t row, pay = static_cast<uint32_t>(e);
+    if (e < E) {
+      int64_t s = src[e], t = dst[e];
+      if (flip & 1) s ^= 1;
+      if (flip & 2) t ^= 1;
+      if (s < 0 || s >= n_cols || t < 0 || t >= n_rows) {
+        flag_error(err_flag, LPG_F_INDEX_RANGE);
+        row = static_cast<uint32_t>(n_rows);
+        s = 0;
+      } else if (loops && s == t) {
+        row = static_cast<uint32_t>(n_rows);
+        if (val) atomicMax(&loop_last[s], static_cast<int32_t>(e));
+      } else {
+        row = static_cast<uint32_t>(t);
+      }
+      if (by_col) pay = static_cast<uint32_t>(s);
+    } else {
+      row = static_cast<uint32_t>(e - E);
+      if (by_col) pay = row;
+    }
+    keys[e] = row;
+    vals[e] = pay;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void rowptr_from_sorted32_kernel(const uint32_t* __restrict__ keys, int64_t M,
+                                                                      int64_t n_rows, int64_t* __restrict__ rowptr) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; k <= M; k += stride) {
+    const int64_t a = (k == 0) ? -1 : static_cast<int64_t>(keys[k - 1]);
+    int64_t b = (k == M) ? n_rows : static_cast<int64_t>(keys[k]);
+    if (b > n_rows) b = n_rows;
+    for (int64_t r = a + 1; r <= b; ++r) rowptr[r] = k;
+  }
+}
+
+// weighted / perm-keeping graphs: the sorted payload is the edge id
+__global__ __launch_bounds__(kBlock) void coo_gather32_kernel(const uint32_t* __restrict__ ids, int64_t M, int64_t E,
+                                                              const int64_t* __restrict__ src, int flip,
+                                                              const float* __restrict__ val,
+                                                              const int32_t* __restrict__ loop_last,
+                                                              int32_t* __restrict__ col_out, float* __restrict__ val_out,
+                                                              int32_t* __restrict__ perm_out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; k < M; k += stride) {
+    const int64_t e = static_cast<int64_t>(ids[k]);
+    int32_t c;
+    float w = 1.f;
+    if (e < E) {
+      c = static_cast<int32_t>((flip & 1) ? (src[e] ^ 1) : src[e]);
+      if (val) w = val[e];
+    } else {
+      c = static_cast<int32_t>(e - E);
+      if (val) {
+        const int32_t last = loop_last[c];
+        if (last >= 0) w = val[last];
+      }
+    }
+    col_out[k] = c;
+    if (val_out) val_out[k] = w;
+    if (perm_out) perm_out[k] = static_cast<int32_t>(e);
   }
 }
 
@@ -273,7 +383,8 @@ __global__ __launch_bounds__(kBlock) void plan_edges_kernel(const int64_t* __res
 
 LPG_EXPORT int64_t lpg_coo_to_csr_bytes(int64_t E, int64_t N, int gcn_self_loops) {
   if (E < 0 || N < 0) return LPG_E_INVALID;
-  return carve(nullptr, E, N, gcn_self_loops).total;
+  const int64_t a = carve(nullptr, E, N, gcn_self_loops).total, b = carve32(nullptr, E, N, gcn_self_loops).total;
+  return a > b ? a : b;
 }
 
 LPG_EXPORT int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const float* val, int64_t E, int64_t n_rows,
@@ -286,12 +397,32 @@ LPG_EXPORT int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const floa
   LPG_REQUIRE(M < (int64_t(1) << 31), "coo_to_csr: more than 2^31-1 edges");
   LPG_REQUIRE(rowptr && (M == 0 || col_out) && (E == 0 || (src && dst)), "coo_to_csr: null pointer");
   LPG_REQUIRE(!val || val_out, "coo_to_csr: val given without val_out");
-  CooWs w = carve(workspace, E, n_rows, gcn_self_loops);
-  if (workspace_bytes < w.total || (!workspace && w.total > 0)) {
-    set_error("coo_to_csr: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)w.total);
+  const bool pairs = M >= kPairSortMin;
+  const int64_t need = pairs ? carve32(workspace, E, n_rows, gcn_self_loops).total
+                             : carve(workspace, E, n_rows, gcn_self_loops).total;
+  if (workspace_bytes < need || (!workspace && need > 0)) {
+    set_error("coo_to_csr: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     return LPG_E_WORKSPACE;
   }
   hipStream_t st = as_stream(stream);
+  if (pairs) {
+    CooWs32 w = carve32(workspace, E, n_rows, gcn_self_loops);
+    const int by_col = !val && !perm_out;
+    if (gcn_self_loops && val) LPG_HIP(hipMemsetAsync(w.loop_last, 0xff, static_cast<size_t>(n_rows + 1) * 4, st));
+    hipLaunchKernelGGL(coo_pairs_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, src, dst, val, E, n_rows, n_cols,
+                       gcn_self_loops, flip, by_col, w.k_in, w.v_in, w.loop_last, err_flag);
+    uint32_t* v_sorted = by_col ? reinterpret_cast<uint32_t*>(col_out) : w.v_out;
+    size_t tmp = w.sort_tmp_bytes;
+    LPG_HIP(rocprim::radix_sort_pairs(w.sort_tmp, tmp, w.k_in, w.k_out, w.v_in, v_sorted, static_cast<size_t>(M), 0u,
+                                      bits_for(n_rows), st, false));
+    hipLaunchKernelGGL(rowptr_from_sorted32_kernel, dim3(grid_for(M + 1)), dim3(kBlock), 0, st, w.k_out, M, n_rows,
+                       rowptr);
+    if (!by_col)
+      hipLaunchKernelGGL(coo_gather32_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, w.v_out, M, E, src, flip, val,
+                         w.loop_last, col_out, val_out, perm_out);
+    return check_launch("coo_to_csr");
+  }
+  CooWs w = carve(workspace, E, n_rows, gcn_self_loops);
   if (gcn_self_loops && val) LPG_HIP(hipMemsetAsync(w.loop_last, 0xff, static_cast<size_t>(n_rows + 1) * 4, st));
   if (M > 0) {
     hipLaunchKernelGGL(coo_keys_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, src, dst, val, E, n_rows, n_cols,

@@ -166,6 +166,41 @@ def test_coo_to_csr_and_gcn_norm(dev, loops):
             assert np.allclose(_np(g.val[:nnz]), val_n, rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("mode", ["col", "weighted", "perm"])
+@pytest.mark.parametrize("loops", [False, True])
+def test_coo_to_csr_pair_sort_keeps_edge_order(dev, loops, mode):
+    """lists of >= 2^18 entries take the stable (row, payload) pair sort (csr_build.hip): rows of ~300 duplicates-rich
+    entries must come out in the original edge order, whatever the payload (source id / edge id)."""
+    import lpgnn_amd
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(7)
+    n, E = 1000, 300_000
+    ei = rand_graph(rng, n, n, E, hub=0.2, empty_frac=0.05)
+    ei[:, :200] = np.stack([np.arange(200), np.arange(200)])        # existing self loops
+    w = rng.uniform(0.1, 2.0, size=ei.shape[1]).astype(np.float32) if mode == "weighted" else None
+    g = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n, n,
+                                           None if w is None else torch.from_numpy(w).to(dev),
+                                           gcn_self_loops=loops, keep_perm=(mode == "perm"))
+    if loops:
+        ei_o, w_o = agg.add_remaining_self_loops(ei, w, n)
+    else:
+        ei_o, w_o = ei, (np.ones(ei.shape[1]) if w is None else w.astype(np.float64))
+    assert ei_o.shape[1] >= 1 << 18
+    rowptr, col, val, perm = agg.coo_to_csr(ei_o[1], ei_o[0], n, w_o)
+    nnz = g.nnz()
+    assert nnz == ei_o.shape[1]
+    assert np.array_equal(_np(g.rowptr), rowptr)
+    assert np.array_equal(_np(g.col[:nnz]), col)
+    if w is not None:
+        assert np.array_equal(_np(g.val[:nnz]), val.astype(np.float32))
+    # the flipped orientation (TwoWL reverse()) through the same path
+    gf = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n, n, gcn_self_loops=loops, flip=3)
+    eif = ei ^ 1
+    eif_o = agg.add_remaining_self_loops(eif, None, n)[0] if loops else eif
+    rp2, col2, _, _ = agg.coo_to_csr(eif_o[1], eif_o[0], n, None)
+    assert np.array_equal(_np(gf.rowptr), rp2) and np.array_equal(_np(gf.col[:gf.nnz()]), col2)
+
+
 def test_coo_to_csr_bad_index_raises(dev):
     import lpgnn_amd
     ei = torch.tensor([[0, 1, 9], [1, 2, 0]], device=dev)
