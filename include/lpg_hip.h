@@ -82,7 +82,10 @@ int lpg_degree_i64(const int64_t* index, int64_t E, int64_t* out, int64_t N, voi
  * perm_out[k] = original edge id of CSR slot k (>= E for appended loops); may be NULL.
  * flip: bit 0 -> source ids are read as id^1, bit 1 -> destination ids as id^1: the two tuple-graph
  * orientations of TwoWL reverse() (edge = (flip(e0), e1), edge_r = (e0, flip(e1)),
- * TwoWL/utils.py:71-78) are built straight from ei2 without materialising them. */
+ * TwoWL/utils.py:71-78) are built straight from ei2 without materialising them.
+ * src == NULL: the column of entry e is e itself -- the grouping a big scatter_add needs (row r lists, in
+ * order, the entries whose index is r; n_cols >= E); lpg_csr_spmm_f32 over it with x = the [E, d] source rows
+ * is scatter_add without atomics. */
 int64_t lpg_coo_to_csr_bytes(int64_t E, int64_t N, int gcn_self_loops);
 int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const float* val, int64_t E,
                    int64_t n_rows, int64_t n_cols, int gcn_self_loops, int flip,

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void coo_keys_kernel(const int64_t* __restr
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < M; e += stride) {
     uint64_t row;
     if (e < E) {
-      int64_t s = src[e], t = dst[e];
+      int64_t s = src ? src[e] : e, t = dst[e];     // src == nullptr: column = entry id
       if (flip & 1) s ^= 1;            // TwoWL reverse(): partner-direction tuple id (utils.py:71-78)
       if (flip & 2) t ^= 1;
       if (s < 0 || s >= n_cols || t < 0 || t >= n_rows) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void coo_pairs_kernel(const int64_t* __rest
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < M; e += stride) {
     uint32_t row, pay = static_cast<uint32_t>(e);
     if (e < E) {
-      int64_t s = src[e], t = dst[e];
+      int64_t s = src ? src[e] : e, t = dst[e];     // src == nullptr: column = entry id
       if (flip & 1) s ^= 1;
       if (flip & 2) t ^= 1;
       if (s < 0 || s >= n_cols || t < 0 || t >= n_rows) {
@@ -180,7 +180,10 @@ __global__ __launch_bounds__(kBlock) void coo_gather32_kernel(const uint32_t* __
     int32_t c;
     float w = 1.f;
     if (e < E) {
-      c = static_cast<int32_t>((flip & 1) ? (src[e] ^ 1) : src[e]);
+      {
+        const int64_t sv = src ? src[e] : e;
+        c = static_cast<int32_t>((flip & 1) ? (sv ^ 1) : sv);
+      }
       if (val) w = val[e];
     } else {
       c = static_cast<int32_t>(e - E);
@@ -220,7 +223,10 @@ __global__ __launch_bounds__(kBlock) void coo_gather_kernel(const uint64_t* __re
     int32_t c;
     float w = 1.f;
     if (e < E) {
-      c = static_cast<int32_t>((flip & 1) ? (src[e] ^ 1) : src[e]);
+      {
+        const int64_t sv = src ? src[e] : e;
+        c = static_cast<int32_t>((flip & 1) ? (sv ^ 1) : sv);
+      }
       if (val) w = val[e];
     } else {
       c = static_cast<int32_t>(e - E);
@@ -395,7 +401,7 @@ LPG_EXPORT int lpg_coo_to_csr(const int64_t* src, const int64_t* dst, const floa
   LPG_REQUIRE(!gcn_self_loops || n_rows == n_cols, "coo_to_csr: self loops need a square matrix");
   const int64_t M = E + (gcn_self_loops ? n_rows : 0);
   LPG_REQUIRE(M < (int64_t(1) << 31), "coo_to_csr: more than 2^31-1 edges");
-  LPG_REQUIRE(rowptr && (M == 0 || col_out) && (E == 0 || (src && dst)), "coo_to_csr: null pointer");
+  LPG_REQUIRE(rowptr && (M == 0 || col_out) && (E == 0 || dst), "coo_to_csr: null pointer");
   LPG_REQUIRE(!val || val_out, "coo_to_csr: val given without val_out");
   const bool pairs = M >= kPairSortMin;
   const int64_t need = pairs ? carve32(workspace, E, n_rows, gcn_self_loops).total

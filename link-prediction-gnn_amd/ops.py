@@ -4,6 +4,7 @@ PyTorch is used only for device memory, streams and dtype bookkeeping; every com
 is a kernel of liblpg_hip.so (include/lpg_hip.h).  All tensors must live on a ROCm device.
 """
 import os
+from collections import OrderedDict
 from typing import Optional
 
 import torch
@@ -64,8 +65,43 @@ def _c(t, dtype=None):
 
 
 # ------------------------------------------------------------------------------ scatter_add
-def scatter_add_rows(src: Optional[torch.Tensor], index: torch.Tensor, out: torch.Tensor):
-    """out[index[e], :] += src[e, :]  (src None => ones, int64 only).  out is [N] or [N, d]."""
+SCATTER_SORT_MIN = 1 << 20          # entries from which float32 row scatters group by destination instead of using atomics
+
+
+def scatter_add_sorts(E, d, dtype):
+    return dtype == torch.float32 and E >= SCATTER_SORT_MIN and d >= 4 and E < (1 << 31)
+
+
+class _ScatterPlans:
+    """destination-grouped form of an index tensor (CSRGraph with column = entry id), memoised on the tensor's identity
+    the way nn.graph_cache memoises edge_index; entries keep the index alive so its storage cannot be recycled."""
+
+    def __init__(self, capacity=2):
+        self.capacity, self._d = capacity, OrderedDict()
+
+    def get(self, index, n_rows):
+        key = (index.data_ptr(), index._version, index.numel(), index.device, n_rows)
+        hit = self._d.get(key)
+        if hit is not None:
+            self._d.move_to_end(key)
+            return hit[0]
+        g = CSRGraph.from_scatter_index(index, n_rows)
+        self._d[key] = (g, index)
+        if len(self._d) > self.capacity:
+            self._d.popitem(last=False)
+        return g
+
+    def clear(self):
+        self._d.clear()
+
+
+_scatter_plans = _ScatterPlans()
+
+
+def scatter_add_rows(src: Optional[torch.Tensor], index: torch.Tensor, out: torch.Tensor, fresh: bool = False):
+    """out[index[e], :] += src[e, :]  (src None => ones, int64 only).  out is [N] or [N, d].
+    fresh: the caller allocated `out` for this call and does not need its old contents (it may be uninitialised
+    when scatter_add_sorts() holds)."""
     lib = _lib.load()
     _need_gpu(index, out, src)
     index = _c(index, torch.int64)
@@ -80,6 +116,16 @@ def scatter_add_rows(src: Optional[torch.Tensor], index: torch.Tensor, out: torc
                    "scatter_add_i64")
     elif out.dtype == torch.float32:
         src = _c(src, torch.float32)
+        if scatter_add_sorts(E, d, out.dtype) and src is not None and out.dim() == 2:
+            # big lists: no atomics.  The entries are grouped by destination once per index tensor (a CSR whose columns
+            # are entry ids, memoised like the GCN graphs) and every call is one gather-reduce over it -- sums in entry
+            # order, reproducible, and 4-5x the rate of float atomics on [E, d] rows
+            g = _scatter_plans.get(index, N)
+            if fresh:
+                g.spmm(src, out=out, use_val=False)
+            else:
+                out += g.spmm(src, use_val=False)
+            return out
         _lib.check(lib.lpg_scatter_add_f32(_ptr(src), _ptr(index), E, d, _ptr(out), N, _ptr(flag), _stream()),
                    "scatter_add_f32")
     else:
@@ -165,6 +211,25 @@ class CSRGraph:
         g = CSRGraph(rowptr, col, val, n_rows, n_cols, e_cap, perm=perm)
         g._build_plan()
         g._finish_build("edge_index")           # one sync per graph build
+        return g
+
+    @staticmethod
+    def from_scatter_index(index, n_rows):
+        """the grouping scatter_add needs: row r lists, in order, the entries e with index[e] == r (column = e)."""
+        lib = _lib.load()
+        _need_gpu(index)
+        dev = index.device
+        dst = _c(index, torch.int64)
+        E = dst.numel()
+        rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+        col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        nbytes = _lib.check(lib.lpg_coo_to_csr_bytes(E, n_rows, 0), "coo_to_csr_bytes")
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        _lib.check(lib.lpg_coo_to_csr(None, _ptr(dst), None, E, n_rows, max(E, 1), 0, 0, _ptr(rowptr), _ptr(col), None,
+                                      None, _ptr(ws), nbytes, _ptr(err_flag(dev)), _stream()), "coo_to_csr")
+        g = CSRGraph(rowptr, col, None, n_rows, E, E)
+        g._build_plan()
+        g._finish_build("scatter_add index")
         return g
 
     @staticmethod

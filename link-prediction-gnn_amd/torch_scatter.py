@@ -42,7 +42,7 @@ def _rows_view(src, index, dim):
     return dim, src, idx, True
 
 
-def _impl_into(src, index, dim, out):
+def _impl_into(src, index, dim, out, fresh=False):
     dim, s, idx, general = _rows_view(src, index, dim)
     if general is None:
         cols = 1
@@ -51,7 +51,7 @@ def _impl_into(src, index, dim, out):
         o = out.view(out.shape[0], cols) if out.dim() > 1 else out
         if not o.is_contiguous():
             raise ValueError("scatter_add: `out` must be contiguous")
-        _ops.scatter_add_rows(s, idx, o)
+        _ops.scatter_add_rows(s, idx, o, fresh)
     else:
         # element-wise: flatten to a 1-D scatter with linearised destination offsets
         src_m = s.movedim(dim, -1)
@@ -77,8 +77,11 @@ def _scatter_add(src, index, dim, dim_size):
         size[d] = 0
     else:
         size[d] = int(index.max()) + 1
-    out = torch.zeros(size, dtype=src.dtype, device=src.device)
-    _impl_into(src, index, dim, out)
+    # big float32 row scatters write every output row themselves (ops.scatter_add_rows, grouped route): no zero fill
+    grouped = d == 0 and index.dim() == 1 and src.dim() == 2 and src.is_cuda and \
+        _ops.scatter_add_sorts(index.numel(), src.shape[1], src.dtype)
+    out = (torch.empty if grouped else torch.zeros)(size, dtype=src.dtype, device=src.device)
+    _impl_into(src, index, dim, out, fresh=True)
     return out
 
 

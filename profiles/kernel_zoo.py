@@ -46,8 +46,17 @@ report("degree int64 (scatter_add ones), E=100M N=5M", timeit(lambda: twowl.degr
 ei_s = ei[:, :10_000_000].contiguous()
 src = torch.randn((10_000_000, d), device=dev)
 out = torch.zeros((N, d), device=dev)
+_min = ops.SCATTER_SORT_MIN
+ops.SCATTER_SORT_MIN = 1 << 62
 report("scatter_add f32 atomics, E=10M d=128", timeit(lambda: ops.scatter_add_rows(src, ei_s[1], out), 5),
        10_000_000 * (8 + d * 4) + 0, note="bound: memory-side float atomics ~1.3 TB/s of added bytes")
+ops.SCATTER_SORT_MIN = _min
+idx_s = ei_s[1].contiguous()
+report("scatter_add f32 grouped by destination (the route lists >= 2^20 take), E=10M d=128",
+       timeit(lambda: ops.scatter_add_rows(src, idx_s, out, True), 5), 10_000_000 * (8 + d * 4) + N * d * 4,
+       note="plan memoised per index tensor; first call adds the grouping (profiles/r01/scatter_add_time.log)")
+ops._scatter_plans.clear()
+del idx_s
 del src, out
 report("coo_to_csr + plan (one-time), E=100M", timeit(lambda: lpgnn_amd.CSRGraph.from_edge_index(ei, N, N), 3, 1), E * 16)
 g = lpgnn_amd.CSRGraph.from_edge_index(ei, N, N, gcn_self_loops=True)

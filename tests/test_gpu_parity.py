@@ -124,6 +124,52 @@ def test_scatter_add_variants(dev):
     assert np.array_equal(_np(got), want)
 
 
+@pytest.mark.parametrize("E", [100_000, 300_000])             # unique-key sort / stable pair sort (csr_build.hip)
+def test_scatter_add_big_float_lists_group_by_destination(dev, monkeypatch, E):
+    """float32 row scatters of >= ops.SCATTER_SORT_MIN entries take the atomic-free route (entries grouped by
+    destination once per index tensor, then one gather-reduce): same sums as the oracle, bitwise reproducible,
+    `out=` accumulates, an edited index tensor is regrouped, out-of-range raises."""
+    from lpgnn_amd import ops
+    from lpgnn_amd.torch_scatter import scatter_add
+    from oracle import aggregation as agg
+    monkeypatch.setattr(ops, "SCATTER_SORT_MIN", 1 << 16)
+    ops._scatter_plans.clear()
+    rng = np.random.default_rng(11)
+    n, d = 3000, 20
+    idx = rng.integers(0, n, size=E)
+    idx[: E // 5] = 17                                           # a heavy destination
+    idx[idx == 5] = 6                                            # and one without entries
+    src = rng.standard_normal((E, d)).astype(np.float32)
+    st, it = torch.from_numpy(src).to(dev), torch.from_numpy(idx).to(dev)
+    assert ops.scatter_add_sorts(E, d, torch.float32)
+    got = scatter_add(st, it, dim=0, dim_size=n)
+    want = agg.scatter_add(src.astype(np.float64), idx, n)
+    scale = agg.scatter_add(np.abs(src).astype(np.float64), idx, n)
+    assert np.all(np.abs(_np(got) - want) <= TOL * scale + 1e-30)
+    assert not _np(got)[5].any()
+    assert len(ops._scatter_plans._d) == 1
+    assert torch.equal(got, scatter_add(st, it, dim=0, dim_size=n))          # reproducible (and the memoised plan)
+    out = torch.full((n, d), 2.0, device=dev)
+    scatter_add(st, it, dim=0, out=out)
+    assert np.all(np.abs(_np(out) - 2.0 - want) <= TOL * (scale + 2.0) + 1e-30)
+    # the atomics route on the same data agrees
+    monkeypatch.setattr(ops, "SCATTER_SORT_MIN", 1 << 40)
+    ref = scatter_add(st, it, dim=0, dim_size=n)
+    monkeypatch.setattr(ops, "SCATTER_SORT_MIN", 1 << 16)
+    assert np.all(np.abs(_np(ref) - _np(got)) <= 2 * TOL * scale + 1e-30)
+    # in-place edit of the index: regrouped, not served from the memo
+    it[:1000] = 5
+    idx2 = idx.copy()
+    idx2[:1000] = 5
+    got2 = scatter_add(st, it, dim=0, dim_size=n)
+    want2 = agg.scatter_add(src.astype(np.float64), idx2, n)
+    assert np.all(np.abs(_np(got2) - want2) <= TOL * scale.max() + 1e-30)
+    it[3] = n
+    with pytest.raises(IndexError):
+        scatter_add(st, it, dim=0, dim_size=n)
+    ops._scatter_plans.clear()
+
+
 def test_scatter_add_out_of_range_raises(dev):
     from lpgnn_amd.torch_scatter import scatter_add
     idx = torch.tensor([0, 5, 2], device=dev)
