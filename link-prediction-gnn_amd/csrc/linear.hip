@@ -274,7 +274,9 @@ LPG_EXPORT int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w
   }
   // split K across the 4 waves when there is more than one K-slice and the problem is small enough
   // to be latency bound (few row tiles); big problems read X once with all columns per wave.
-  if (k > KT && n <= (int64_t(1) << 16)) {
+  // (measured, k = 288 / 448, m = 128: the split form wins up to n ~ 6 K -- 18 vs 32 us at n <= 2 K -- and loses from
+  // 8 K on, 4.5x at n = 50 K: it re-reads X once per 32 output columns; profiles/r01/linear_small_n.log)
+  if (k > KT && n <= 6144) {
     const int64_t gx = ceil_div(n, 32), gy = ceil_div(m, 32);
     LPG_REQUIRE(gy < 65536, "linear: grid too large");
     hipLaunchKernelGGL(linear_splitk_f32_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)),
