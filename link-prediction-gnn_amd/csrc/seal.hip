@@ -739,7 +739,10 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   LPG_REQUIRE(max_neighbors >= 2 && max_neighbors <= MAXN, "seal_subgraphs: max_neighbors must be in [2, %d]", MAXN);
   if (B == 0) return LPG_OK;
   LPG_REQUIRE(adj_rowptr && pairs && nodes && n_nodes && tags && adj_bits && capped, "seal_subgraphs: null pointer");
-  const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
+  // a workgroup per pair, NOT a persistent grid striding the list: the cost of a pair spans 10x (hub-rich subgraphs) and
+  // a static share of ~24 pairs per workgroup left the chip waiting for the unluckiest one (100 K collab-shaped pairs:
+  // 0.755 ms with 4096 workgroups, 0.581 ms with one per pair -- the hardware dispatcher is the work queue)
+  const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
   hipLaunchKernelGGL(seal_subgraph_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), adj_rowptr, adj_col,
                      n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag,
                      tag_present, hub_bits ? hub_index : nullptr, hub_bits, static_cast<int>(hub_words));
@@ -795,7 +798,7 @@ int seal_features_entry(const int32_t* nodes, const int64_t* node_off, const int
   LPG_REQUIRE(nodes && node_off && tags && x && (emb_dim == 0 || emb), "seal_features: null pointer");
   LPG_REQUIRE(ldx < (int64_t(1) << 30), "seal_features: row too wide");
   const int wstore = static_cast<int>(zero_pad ? ldx : T + emb_dim);
-  const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
+  const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));   // a workgroup per subgraph (see lpg_seal_subgraphs)
   hipLaunchKernelGGL(seal_features_kernel<TO>, dim3(grid), dim3(kBlock), 0, as_stream(stream), nodes, node_off, tags,
                      tag_map, tag_map_len, T, emb, emb_dim, B, x, ldx, wstore, err_flag);
   return check_launch("seal_features");
@@ -829,7 +832,7 @@ LPG_EXPORT int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_
   LPG_REQUIRE(nodes && node_off && tags && w1_tag && p_table && h1, "seal_h1_tables: null pointer");
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   LPG_REQUIRE(al16(w1_tag) && al16(p_table) && al16(h1), "seal_h1_tables: tables and output must be 16-byte aligned");
-  const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
+  const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));   // a workgroup per subgraph (see lpg_seal_subgraphs)
   hipLaunchKernelGGL(seal_h1_tables_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), nodes, node_off, tags, tag_map,
                      tag_map_len, T, w1_tag, p_table, n_graph, B, h1, ldh, err_flag);
   return check_launch("seal_h1_tables");
@@ -840,7 +843,7 @@ LPG_EXPORT int lpg_seal_sortpool_f32(const float* z, int64_t ldz, const float* k
   LPG_REQUIRE(B >= 0 && k >= 1 && C >= 1 && ldz >= C, "seal_sortpool: bad sizes");
   if (B == 0) return LPG_OK;
   LPG_REQUIRE(z && key && node_off && out, "seal_sortpool: null pointer");
-  const int grid = static_cast<int>(B < 256 * 16 ? B : 256 * 16);
+  const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));   // a workgroup per subgraph (see lpg_seal_subgraphs)
   LPG_REQUIRE(k * C < (int64_t(1) << 30), "seal_sortpool: k * C too large");
   const int vec = C % 4 == 0 && ldz % 4 == 0 && reinterpret_cast<uintptr_t>(z) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(out) % 16 == 0;
