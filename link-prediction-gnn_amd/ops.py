@@ -149,14 +149,15 @@ def rows_add_distinct(src: torch.Tensor, index: torch.Tensor, out: torch.Tensor)
 
 def degree(index: torch.Tensor, n: int) -> torch.Tensor:
     """int64 histogram of `index` over [0, n): the reference's degree() (TwoWL/utils.py:8-10) without
-    materialising the ones vector; big lists are counted by sorting (no atomics)."""
+    materialising the ones vector; lists of >= 2 M entries are counted without atomics (one radix pass over the high
+    bits, then 32 K-bin LDS histograms; csrc/degree.hip)."""
     lib = _lib.load()
     _need_gpu(index)
     index = _c(index, torch.int64)
     out = torch.zeros(n, dtype=torch.int64, device=index.device)
     E = index.numel()
     nbytes = _lib.check(lib.lpg_degree_i64_bytes(E, n), "degree_bytes")
-    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=index.device) if E >= (1 << 22) else None
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=index.device) if E >= (1 << 21) else None
     _lib.check(lib.lpg_degree_i64(_ptr(index), E, _ptr(out), n, _ptr(ws), nbytes if ws is not None else 0,
                                   _ptr(err_flag(index.device)), _stream()), "degree_i64")
     maybe_check(index.device, "degree index")

@@ -68,14 +68,17 @@ def test_rows_add_distinct(dev):
     assert float(o.sum()) == 8.0
 
 
-def test_degree_sorted_path_bit_exact(dev):
-    """E >= 4 M takes the sort-and-count path (csrc/degree.hip): equal to numpy's bincount and to the atomic
-    kernels, including odd lengths, a hub destination, empty nodes and out-of-range indices (skipped + flagged)."""
+@pytest.mark.parametrize("n", [20_000, 32_768, 300_001, 1_000_000 + 32_768 * 3, 3_000_000])
+def test_degree_sorted_path_bit_exact(dev, n):
+    """E >= 4 M takes the atomic-free paths of csrc/degree.hip -- one radix pass over the high bits + 32 K-bin LDS
+    histograms (no pass at all for n <= 32 K; bucket borders on and off n), or the full sort when E < 2 n: equal to
+    numpy's bincount and to the atomic kernels, including odd lengths, a hub destination, empty nodes and
+    out-of-range indices (skipped + flagged)."""
     import lpgnn_amd
     from lpgnn_amd import ops
     from lpgnn_amd.torch_scatter import scatter_add
     rng = np.random.default_rng(5)
-    n, E = 300_001, (1 << 22) + 12345
+    E = (1 << 22) + 12345
     idx = rng.integers(0, n, size=E).astype(np.int64)
     idx[: E // 10] = 777                                   # a hub
     idx[idx % 5 == 3] = 4                                  # many empty nodes
@@ -83,6 +86,10 @@ def test_degree_sorted_path_bit_exact(dev):
     got = ops.degree(t, n)
     want = np.bincount(idx, minlength=n)
     assert got.dtype == torch.int64 and np.array_equal(_np(got), want)
+    idx[-5:] = n - 1                                       # the last bin, next to the out-of-range sentinel
+    t = torch.from_numpy(idx).to(dev)
+    got = ops.degree(t, n)
+    assert np.array_equal(_np(got), np.bincount(idx, minlength=n))
     assert torch.equal(scatter_add(torch.ones_like(t), t, dim_size=n), got)        # the atomic kernels agree
     assert torch.equal(ops.degree(t[1:], n), torch.from_numpy(np.bincount(idx[1:], minlength=n)).to(dev))   # 8-byte aligned view
     bad = t.clone()
