@@ -65,6 +65,7 @@ def _c(t, dtype=None):
 
 
 # ------------------------------------------------------------------------------ scatter_add
+DEGREE_SORT_MIN = 1 << 21           # entries from which int64 histograms take the atomic-free path of csrc/degree.hip
 SCATTER_SORT_MIN = 1 << 20          # entries from which float32 row scatters group by destination instead of using atomics
 
 
@@ -147,17 +148,20 @@ def rows_add_distinct(src: torch.Tensor, index: torch.Tensor, out: torch.Tensor)
     return out
 
 
-def degree(index: torch.Tensor, n: int) -> torch.Tensor:
+def degree(index: torch.Tensor, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """int64 histogram of `index` over [0, n): the reference's degree() (TwoWL/utils.py:8-10) without
     materialising the ones vector; lists of >= 2 M entries are counted without atomics (one radix pass over the high
     bits, then 32 K-bin LDS histograms; csrc/degree.hip)."""
     lib = _lib.load()
     _need_gpu(index)
     index = _c(index, torch.int64)
-    out = torch.zeros(n, dtype=torch.int64, device=index.device)
+    if out is None:
+        out = torch.zeros(n, dtype=torch.int64, device=index.device)
+    elif out.dtype != torch.int64 or out.shape != (n,) or not out.is_contiguous():
+        raise ValueError("degree: `out` must be a contiguous int64 [n] tensor (counts are added to it)")
     E = index.numel()
     nbytes = _lib.check(lib.lpg_degree_i64_bytes(E, n), "degree_bytes")
-    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=index.device) if E >= (1 << 21) else None
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=index.device) if E >= DEGREE_SORT_MIN else None
     _lib.check(lib.lpg_degree_i64(_ptr(index), E, _ptr(out), n, _ptr(ws), nbytes if ws is not None else 0,
                                   _ptr(err_flag(index.device)), _stream()), "degree_i64")
     maybe_check(index.device, "degree index")

@@ -51,6 +51,13 @@ def _impl_into(src, index, dim, out, fresh=False):
         o = out.view(out.shape[0], cols) if out.dim() > 1 else out
         if not o.is_contiguous():
             raise ValueError("scatter_add: `out` must be contiguous")
+        if s.dtype == torch.int64 and s.dim() == 1 and o.dim() == 1 and idx.numel() >= _ops.DEGREE_SORT_MIN \
+                and s.is_cuda and bool((s == 1).all()):
+            # the reference's degree() is exactly this call -- scatter_add(ones_like(ei[1]), ei[1], dim_size=N)
+            # (TwoWL/utils.py:8-10): a big list of ones is a histogram and takes the atomic-free degree path
+            # (one pass over src to see that it is all ones: 0.15 ms per 100 M against 9 ms of scattered atomics saved)
+            _ops.degree(idx, o.shape[0], out=o)
+            return
         _ops.scatter_add_rows(s, idx, o, fresh)
     else:
         # element-wise: flatten to a 1-D scatter with linearised destination offsets

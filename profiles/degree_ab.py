@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""degree() at scale: sort-and-count (csrc/degree.hip) vs the atomic kernels (scatter.hip), |E| = 100 M RMAT destinations."""
+"""degree() at scale: the atomic-free path (csrc/degree.hip) vs the atomic kernels (scatter.hip), RMAT destinations."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,6 +19,11 @@ for N, E in ((5_000_000, 100_000_000), (10_000_000, 200_000_000), (576_289, 60_6
     ones = torch.ones_like(idx)
     a = ops.degree(idx, N); b = scatter_add(ones, idx, dim_size=N)
     assert torch.equal(a, b)
-    print(f"N={N} E={E}: atomic-free {T(lambda: ops.degree(idx, N)):.3f} ms, atomics {T(lambda: scatter_add(ones, idx, dim_size=N)):.3f} ms "
+    t_deg = T(lambda: ops.degree(idx, N))
+    t_drop = T(lambda: scatter_add(ones, idx, dim_size=N))      # the reference's spelling: a big list of ones is routed to degree()
+    keep, ops.DEGREE_SORT_MIN = ops.DEGREE_SORT_MIN, 1 << 62
+    t_atom = T(lambda: scatter_add(ones, idx, dim_size=N))
+    ops.DEGREE_SORT_MIN = keep
+    print(f"N={N} E={E}: degree() {t_deg:.3f} ms, scatter_add(ones_like(idx), idx) {t_drop:.3f} ms, the atomic kernels {t_atom:.3f} ms "
           f"(index stream alone at 6.29 TB/s: {E * 8 / 6.29e9:.3f} ms)", flush=True)
     del ei, idx, ones

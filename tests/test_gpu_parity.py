@@ -69,7 +69,7 @@ def test_rows_add_distinct(dev):
 
 
 @pytest.mark.parametrize("n", [20_000, 32_768, 300_001, 1_000_000 + 32_768 * 3, 3_000_000])
-def test_degree_sorted_path_bit_exact(dev, n):
+def test_degree_sorted_path_bit_exact(dev, n, monkeypatch):
     """E >= 4 M takes the atomic-free paths of csrc/degree.hip -- one radix pass over the high bits + 32 K-bin LDS
     histograms (no pass at all for n <= 32 K; bucket borders on and off n), or the full sort when E < 2 n: equal to
     numpy's bincount and to the atomic kernels, including odd lengths, a hub destination, empty nodes and
@@ -90,7 +90,16 @@ def test_degree_sorted_path_bit_exact(dev, n):
     t = torch.from_numpy(idx).to(dev)
     got = ops.degree(t, n)
     assert np.array_equal(_np(got), np.bincount(idx, minlength=n))
-    assert torch.equal(scatter_add(torch.ones_like(t), t, dim_size=n), got)        # the atomic kernels agree
+    # the reference's own spelling, scatter_add(ones_like(idx), idx): a big list of ones is routed to the same path ...
+    assert torch.equal(scatter_add(torch.ones_like(t), t, dim_size=n), got)
+    acc = torch.full((n,), 3, dtype=torch.int64, device=dev)
+    scatter_add(torch.ones_like(t), t, out=acc)
+    assert torch.equal(acc, got + 3)
+    twos = torch.full_like(t, 2)                                                   # ... anything else is not
+    assert torch.equal(scatter_add(twos, t, dim_size=n), 2 * got)
+    monkeypatch.setattr(ops, "DEGREE_SORT_MIN", 1 << 62)                           # and the atomic kernels agree
+    assert torch.equal(scatter_add(torch.ones_like(t), t, dim_size=n), got)
+    monkeypatch.undo()
     assert torch.equal(ops.degree(t[1:], n), torch.from_numpy(np.bincount(idx[1:], minlength=n)).to(dev))   # 8-byte aligned view
     bad = t.clone()
     bad[123] = n + 5
