@@ -860,6 +860,51 @@ def test_spmm_large_rmat_properties(dev):
         assert torch.all((y[r].double() - ref).abs() <= TOL * mg + 1e-30)
 
 
+def test_full_size_headline_instance_properties(dev):
+    """The bench's own instance -- RMAT |V| = 5 M, |E| = 100 M, d = 128 fp32 (BASELINE north-star target) -- through
+    size-independent properties: degree() == bincount (int64, bit-exact), CSR row lengths == in-degrees and every
+    row's columns == the sources in edge order on a sample, column checksum of Y in fp64, exact scaling by 2,
+    bitwise reproducibility, sampled rows against an fp64 gather-sum; and the scatter_add spelling of the same
+    aggregation (grouped route) against the SpMM on a 10 M-edge slice."""
+    import bench
+    import lpgnn_amd
+    from lpgnn_amd import ops
+    from lpgnn_amd.torch_scatter import scatter_add
+    N, E, d = 5_000_000, 100_000_000, 128
+    ei = bench.rmat_edges(N, E, 5, dev)
+    deg = ops.degree(ei[1], N)
+    assert torch.equal(deg, torch.bincount(ei[1], minlength=N))
+    g = lpgnn_amd.CSRGraph.from_edge_index(ei, N, N)
+    assert g.nnz() == E
+    assert torch.equal(g.rowptr[1:] - g.rowptr[:-1], deg)
+    rows = torch.cat([torch.randint(0, N, (40,), device=dev), deg.topk(3).indices])      # incl. the hubs
+    for r in rows.tolist():
+        b, e = int(g.rowptr[r]), int(g.rowptr[r + 1])
+        assert torch.equal(g.col[b:e].long(), ei[0][ei[1] == r])                           # stable: edge order kept
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1005)
+    x = torch.randn((N, d), generator=gen, device=dev)
+    y = g.spmm(x)
+    outdeg = torch.bincount(ei[0], minlength=N).double()
+    want, mag = outdeg @ x.double(), outdeg @ x.double().abs()
+    assert torch.all((y.double().sum(0) - want).abs() <= 1e-6 * mag)
+    assert torch.equal(g.spmm(2.0 * x), 2.0 * y)
+    assert torch.equal(g.spmm(x), y)
+    for r in rows.tolist():
+        src = ei[0][ei[1] == r]
+        ref, mg = x[src].double().sum(0), x[src].double().abs().sum(0)
+        assert torch.all((y[r].double() - ref).abs() <= TOL * mg + 1e-30)
+    del y, g
+    m = 10_000_000
+    msg = x[ei[0, :m]]                                                                     # the [E, d] message tensor
+    ys = scatter_add(msg, ei[1, :m], dim=0, dim_size=N)
+    gs = lpgnn_amd.CSRGraph.from_edge_index(ei[:, :m].contiguous(), N, N)
+    ref = gs.spmm(x)
+    scale = gs.spmm(x.abs())
+    assert torch.all((ys - ref).abs() <= 2 * TOL * scale + 1e-30)
+    ops._scatter_plans.clear()
+
+
 def test_captured_forward_matches_eager(dev, tw):
     """hipGraph replay of the scoring forward == the eager forward, bit for bit."""
     from lpgnn_amd import twowl
