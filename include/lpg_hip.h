@@ -334,6 +334,17 @@ int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_off, const 
  * linear on the concat) the kernel also writes head_a16 [total,16] = [Z_1|Z_2|Z_3] @ head_k1; cat may then be NULL
  * (the 96-wide concat is never written).  The aggregation runs on the bf16 matrix cores through an exact three-way
  * bf16 split of H (0/1/2 adjacency entries are exact in bf16); LPG_SEAL_CONV_FP32=1 keeps the fp32 MFMA form. */
+/* The index of a batch of subgraphs in one launch: node_off [B + 1] = exclusive scan of the sizes n_nodes [B]
+ * (the row offsets of the block-diagonal batch, SEAL/config/data.py:94-117 stacks per-graph arrays); tag_map
+ * [n_tags] = rank of every PRESENT tag among the present ones, -1 for the others -- the global tag compaction of
+ * SEAL/config/subgraph.py:84-101 (ascending tags -> 0 .. T-1) from the presence bytes lpg_seal_subgraphs filled
+ * (tag_present may be NULL: no map); head [4] = {total vertices, *err_flag, T, 0} for the caller's single host
+ * read.  Workspace only for B > 2^18 (lpg_seal_batch_index_bytes). */
+int64_t lpg_seal_batch_index_bytes(int64_t B);
+int lpg_seal_batch_index(const int32_t* n_nodes, int64_t B, int64_t* node_off, const uint8_t* tag_present,
+                         int64_t n_tags, int32_t* tag_map, const int32_t* err_flag, int64_t* head,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
 /* first[w], w = 0 .. n_windows (n_windows + 1 entries) for lpg_seal_conv_stack_f32: one launch instead of a
  * searchsorted / arange / clamp chain; window_rows <= 128. */
 int lpg_seal_conv_windows(const int64_t* node_off, int64_t B, int64_t n_windows, int64_t window_rows,

@@ -8,6 +8,7 @@
 // 128x128 bit matrix, and both BFS runs are level-synchronous bitset sweeps.
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "lpg_common.hpp"
 
@@ -727,6 +728,110 @@ __global__ __launch_bounds__(kBlock) void softmax2_kernel(const float* __restric
     score[b] = e1 / (e0 + e1);
   }
 }
+
+// ---- batch index: node_off = exclusive scan of the subgraph sizes, the tag map = ranks of the present tags, and
+// one 4-word head {total vertices, error flag, distinct tags, 0} for the batch's single host read.  One launch, two
+// workgroups (a dozen tiny scan / elementwise launches before: 40 of the 210 us of fb-pages-food's structure stage).
+constexpr int kIdxBlock = 1024;
+constexpr int64_t kIdxOneBlockMax = int64_t(1) << 18;     // beyond: the sizes are scanned by rocPRIM first
+
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int64_t up = __shfl_up(v, o, 64);
+    if (lane >= o) v += up;
+  }
+  return v;
+}
+
+// inclusive block scan of one value per thread on top of `carry`; returns the thread's EXCLUSIVE prefix, updates carry
+__device__ __forceinline__ int64_t block_excl_scan(int64_t mine, int64_t& carry, int64_t* wsum, int t) {
+  const int lane = t & 63, wv = t >> 6;
+  const int64_t incl = wave_incl_scan(mine, lane);
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int64_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kIdxBlock / 64; ++w) {
+    const int64_t x = wsum[w];
+    before += w < wv ? x : 0;
+    all += x;
+  }
+  const int64_t excl = carry + before + incl - mine;
+  carry += all;
+  __syncthreads();                                 // wsum is reused by the next tile
+  return excl;
+}
+
+__global__ __launch_bounds__(kIdxBlock) void seal_batch_index_kernel(const int32_t* __restrict__ n, int64_t B,
+                                                                     int64_t* __restrict__ off, int scan_sizes,
+                                                                     const uint8_t* __restrict__ present, int K,
+                                                                     int32_t* __restrict__ tag_map,
+                                                                     const int32_t* __restrict__ err_flag,
+                                                                     int64_t* __restrict__ head) {
+  __shared__ int64_t wsum[kIdxBlock / 64];
+  const int t = threadIdx.x;
+  int64_t carry = 0;
+  if (blockIdx.x == 0) {
+    if (scan_sizes) {
+      for (int64_t base = 0; base < B; base += 4 * kIdxBlock) {
+        const int64_t i0 = base + 4 * t;
+        int v[4] = {0, 0, 0, 0};
+        if (i0 + 3 < B) {
+          const int4 q = *reinterpret_cast<const int4*>(n + i0);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = i0 + j < B ? n[i0 + j] : 0;
+        }
+        int64_t run = block_excl_scan(static_cast<int64_t>(v[0]) + v[1] + v[2] + v[3], carry, wsum, t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          run += v[j];
+          if (i0 + j < B) off[i0 + j + 1] = run;
+        }
+      }
+      if (t == 0) off[0] = 0;
+    } else {
+      carry = off[B];                                // scanned by the caller (rocPRIM) on the same stream
+    }
+    if (t == 0) {
+      head[0] = carry;
+      head[1] = err_flag ? err_flag[0] : 0;
+      head[3] = 0;
+      if (!present) head[2] = 0;
+    }
+  } else if (present) {
+    // 16 presence bytes per thread: the whole DRNL tag range (16 258 entries) is ONE tile, one block scan
+    for (int base = 0; base < K; base += 16 * kIdxBlock) {
+      const int i0 = base + 16 * t;
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (i0 + 15 < K && (reinterpret_cast<uintptr_t>(present) & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4*>(present + i0);
+        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+      } else {
+        for (int j = 0; j < 16; ++j)
+          if (i0 + j < K) w[j >> 2] |= static_cast<uint32_t>(present[i0 + j]) << (8 * (j & 3));
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cnt += ((w[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0;
+      int64_t rank = block_excl_scan(cnt, carry, wsum, t);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const bool p = ((w[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0;
+        if (i0 + j < K) tag_map[i0 + j] = p ? static_cast<int32_t>(rank) : -1;
+        rank += p;
+      }
+    }
+    if (t == 0) head[2] = carry;
+  }
+}
+
+struct I32ToI64 {
+  __device__ int64_t operator()(int32_t v) const { return v; }
+};
+using SizeIt = rocprim::transform_iterator<const int32_t*, I32ToI64, int64_t>;
 }  // namespace
 
 LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
@@ -858,4 +963,36 @@ LPG_EXPORT int lpg_softmax2_pos_score_f32(const float* pre_y, int64_t B, float* 
   LPG_REQUIRE(pre_y && score, "softmax2: null pointer");
   hipLaunchKernelGGL(softmax2_kernel, dim3(grid_for(B)), dim3(kBlock), 0, as_stream(stream), pre_y, B, score);
   return check_launch("softmax2");
+}
+
+LPG_EXPORT int64_t lpg_seal_batch_index_bytes(int64_t B) {
+  if (B < 0) return LPG_E_INVALID;
+  if (B <= kIdxOneBlockMax) return 0;
+  size_t bytes = 0;
+  (void)rocprim::inclusive_scan(nullptr, bytes, SizeIt(nullptr, I32ToI64{}),
+                                static_cast<int64_t*>(nullptr), static_cast<size_t>(B), rocprim::plus<int64_t>(),
+                                hipStream_t(0), false);
+  return lpg::align_up(static_cast<int64_t>(bytes), 256);
+}
+
+LPG_EXPORT int lpg_seal_batch_index(const int32_t* n_nodes, int64_t B, int64_t* node_off, const uint8_t* tag_present,
+                                    int64_t n_tags, int32_t* tag_map, const int32_t* err_flag, int64_t* head,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  LPG_REQUIRE(B >= 0 && n_tags >= 0 && n_tags < (int64_t(1) << 30), "seal_batch_index: bad sizes");
+  LPG_REQUIRE(node_off && head && (B == 0 || n_nodes) && (!tag_present || tag_map), "seal_batch_index: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int one_block = B <= kIdxOneBlockMax;
+  if (!one_block) {
+    size_t bytes = static_cast<size_t>(lpg_seal_batch_index_bytes(B));
+    if (!workspace || workspace_bytes < static_cast<int64_t>(bytes)) {
+      lpg::set_error("seal_batch_index: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)bytes);
+      return LPG_E_WORKSPACE;
+    }
+    LPG_HIP(hipMemsetAsync(node_off, 0, 8, st));
+    LPG_HIP(rocprim::inclusive_scan(workspace, bytes, SizeIt(n_nodes, I32ToI64{}), node_off + 1,
+                                    static_cast<size_t>(B), rocprim::plus<int64_t>(), st, false));
+  }
+  hipLaunchKernelGGL(seal_batch_index_kernel, dim3(tag_present ? 2 : 1), dim3(kIdxBlock), 0, st, n_nodes, B, node_off,
+                     one_block, tag_present, static_cast<int>(n_tags), tag_map, err_flag, head);
+  return lpg::check_launch("seal_batch_index");
 }

@@ -97,29 +97,58 @@ class SubgraphBatch:
         self.B = pairs.shape[0]
         self._off = None
         self._total = None
+        self._tag_map = None
+        self._head = None
+        self._n_tags = None
+
+    def _index(self):
+        """node offsets, tag map and the head {total, error flag, distinct tags} in ONE launch (lpg_seal_batch_index)."""
+        if self._off is None:
+            lib = _lib.load()
+            dev = self.n.device
+            P = _ops._ptr
+            present = self.tag_present
+            K = present.numel() if present is not None else 0
+            self._off = torch.empty(self.B + 1, dtype=torch.int64, device=dev)
+            self._tag_map = torch.empty(K, dtype=torch.int32, device=dev) if K else None
+            self._head = torch.empty(4, dtype=torch.int64, device=dev)
+            n = self.n if self.n.is_contiguous() else self.n.contiguous()
+            nbytes = _lib.check(lib.lpg_seal_batch_index_bytes(self.B), "seal_batch_index_bytes")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+            _lib.check(lib.lpg_seal_batch_index(P(n), self.B, P(self._off), P(present), K, P(self._tag_map),
+                                                P(_ops.err_flag(dev)), P(self._head), P(ws), nbytes, _ops._stream()),
+                       "seal_batch_index")
+            self._total = self._n_tags = None
+
+    def _read_head(self):
+        """the batch's one host read: vertex total, the extraction's index check, number of distinct tags."""
+        if self._total is None:
+            self._index()
+            total, flag, n_tags, _ = self._head.tolist()
+            self._total, self._n_tags = int(total), int(n_tags)
+            if flag and _ops._CHECK:
+                _ops.err_flag(self._head.device).zero_()
+                raise IndexError(f"lpgnn_amd: candidate pair / node id out of range (flag={int(flag)})")
 
     def total(self):
         """number of vertices in the batch (one host sync, cached).  The extraction's index check rides on the same
         transfer: the error flag comes back with the total instead of in a sync of its own."""
-        if self._total is None:
-            off = self.node_off()
-            if _ops._CHECK and not torch.cuda.is_current_stream_capturing():
-                both = torch.stack([off[-1], _ops.err_flag(off.device)[0].to(torch.int64)]).tolist()
-                self._total = int(both[0])
-                if both[1]:
-                    _ops.err_flag(off.device).zero_()
-                    raise IndexError(f"lpgnn_amd: candidate pair / node id out of range (flag={int(both[1])})")
-            else:
-                self._total = int(off[-1].item())
+        self._read_head()
         return self._total
 
     def node_off(self):
         """exclusive prefix sum of the subgraph sizes, int64 [B+1]; computed once per batch."""
-        if self._off is None:
-            off = torch.zeros(self.B + 1, dtype=torch.int64, device=self.n.device)
-            off[1:] = torch.cumsum(self.n.to(torch.int64), 0)
-            self._off = off
+        self._index()
         return self._off
+
+    def tag_map(self):
+        """(tag_map int32 [TAG_BOUND + 1], T): ascending present tags -> 0..T-1, -1 elsewhere; needs tag_present."""
+        self._read_head()
+        return self._tag_map, self._n_tags
+
+    def invalidate(self):
+        """the sizes / tags were edited in place (capped pairs replayed): recompute the index on next use"""
+        self._off = self._total = self._tag_map = self._head = self._n_tags = None
 
 
 CAP_POLICY = {"report": 0, "device": 1}
@@ -265,7 +294,7 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
             ii = torch.as_tensor(idx, device=batch.n.device)
             batch.nodes[ii], batch.n[ii], batch.tags[ii], batch.adj_bits[ii] = sub.nodes, sub.n, sub.tags, sub.adj_bits
             batch.tag_present |= sub.tag_present          # capped pairs came back with n = 0 (no tags) the first time
-            batch._off = batch._total = None                   # the sizes changed
+            batch.invalidate()                                 # the sizes changed
     labels = torch.cat([torch.zeros(len(negative), dtype=torch.uint8), torch.ones(len(positive), dtype=torch.uint8)])
     tag_map, tags_size = compact_tag_map(batch)
     return batch, labels.reshape(-1, 1), tags_size, tag_map, graph
@@ -281,12 +310,11 @@ def compact_tag_map(batch):
     # presence table instead of a sort-based unique over [B, 128] tags (0.32 -> 0.1 ms for 100 K pairs): a DRNL
     # tag on <= 128 vertices is at most 1 + 127 + 127 * 127; slot 0 takes the -1 padding
     dev = batch.tags.device
-    if batch.tag_present is not None:                        # filled by the extraction kernel as it wrote the tags
-        present = batch.tag_present
-    else:
-        present = torch.zeros(_TAG_BOUND + 2, dtype=torch.uint8, device=dev)
-        present[batch.tags.reshape(-1).long() + 1] = 1
-        present = present[1:]
+    if batch.tag_present is not None:                        # filled by the extraction kernel as it wrote the tags:
+        return batch.tag_map()                               # ranked with the batch's offsets, one launch, one host read
+    present = torch.zeros(_TAG_BOUND + 2, dtype=torch.uint8, device=dev)
+    present[batch.tags.reshape(-1).long() + 1] = 1
+    present = present[1:]
     # ascending tags -> 0..T-1 is an exclusive scan of the presence table; ONE host read (T), no nonzero / max round trips
     rank = torch.cumsum(present, 0, dtype=torch.int32)
     tag_map = torch.where(present != 0, rank - 1, torch.full_like(rank, -1))

@@ -860,6 +860,33 @@ def test_spmm_large_rmat_properties(dev):
         assert torch.all((y[r].double() - ref).abs() <= TOL * mg + 1e-30)
 
 
+@pytest.mark.parametrize("B", [0, 1, 5, 4096, 4097, 100_000, 300_000])
+def test_seal_batch_index(dev, B):
+    """lpg_seal_batch_index: node offsets == exclusive cumsum of the sizes (one workgroup up to 2^18 subgraphs, rocPRIM
+    beyond), tag map == ranks of the present tags, head == {total, flag, T, 0}."""
+    from lpgnn_amd import seal, ops
+    rng = np.random.default_rng(B + 3)
+    n = rng.integers(0, 129, size=B).astype(np.int32)
+    K = seal._TAG_BOUND + 1
+    present = (rng.random(K) < 0.01).astype(np.uint8)
+    present[[0, 1, K - 1]] = 1
+    pairs = torch.zeros((B, 2), dtype=torch.int64, device=dev)
+    batch = seal.SubgraphBatch(pairs, None, torch.from_numpy(n).to(dev), None, None, None, torch.from_numpy(present).to(dev))
+    off = _np(batch.node_off())
+    assert off.dtype == np.int64 and np.array_equal(off, np.concatenate([[0], np.cumsum(n.astype(np.int64))]))
+    assert batch.total() == int(n.sum())
+    tm, T = batch.tag_map()
+    want = np.where(present != 0, np.cumsum(present.astype(np.int64)) - 1, -1)
+    assert T == int(present.sum()) and np.array_equal(_np(tm), want)
+    nomap = seal.SubgraphBatch(pairs, None, torch.from_numpy(n).to(dev), None, None, None, None)
+    assert nomap.total() == int(n.sum()) and np.array_equal(_np(nomap.node_off()), off)
+    ops.err_flag(dev)[0] = 4                                   # a flagged extraction surfaces with the head
+    flagged = seal.SubgraphBatch(pairs, None, torch.from_numpy(n).to(dev), None, None, None, None)
+    with pytest.raises(IndexError):
+        flagged.total()
+    assert int(ops.err_flag(dev)[0]) == 0
+
+
 def test_full_size_headline_instance_properties(dev):
     """The bench's own instance -- RMAT |V| = 5 M, |E| = 100 M, d = 128 fp32 (BASELINE north-star target) -- through
     size-independent properties: degree() == bincount (int64, bit-exact), CSR row lengths == in-degrees and every
