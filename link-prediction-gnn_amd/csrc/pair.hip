@@ -49,6 +49,72 @@ __global__ __launch_bounds__(kBlock) void pair_mul_kernel(const float* __restric
   }
 }
 
+// Row-tiled forms for d = 4 * 2^k <= 1024 (every width the models use): a thread keeps ONE column chunk and walks rows,
+// so the (row, column) split is computed once instead of a 64-bit division per element, and four rows are in flight
+// per thread -- all index loads, then all row loads from clamped addresses, then the stores.
+constexpr int kRowsU = 4;
+__global__ __launch_bounds__(kBlock) void embedding_rows4_kernel(const float* __restrict__ table, int64_t n_rows,
+                                                                 int64_t d, int dv, const int64_t* __restrict__ idx,
+                                                                 int64_t n, float* __restrict__ out, int32_t* err_flag) {
+  const int cv = threadIdx.x % dv, rin = threadIdx.x / dv, rpb = kBlock / dv;
+  const int64_t step = static_cast<int64_t>(gridDim.x) * rpb * kRowsU;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * rpb * kRowsU; base < n; base += step) {
+    int64_t r[kRowsU];
+    bool ok[kRowsU];
+#pragma unroll
+    for (int u = 0; u < kRowsU; ++u) {
+      const int64_t i = base + u * rpb + rin;
+      r[u] = idx[i < n ? i : n - 1];
+    }
+    float4 v[kRowsU];
+#pragma unroll
+    for (int u = 0; u < kRowsU; ++u) {
+      const int64_t i = base + u * rpb + rin;
+      const bool in = r[u] >= 0 && r[u] < n_rows;
+      if (i < n && !in) flag_error(err_flag, LPG_F_INDEX_RANGE);
+      ok[u] = i < n && in;
+      v[u] = *reinterpret_cast<const float4*>(table + (in ? r[u] : 0) * d + 4 * cv);
+    }
+#pragma unroll
+    for (int u = 0; u < kRowsU; ++u)
+      if (ok[u]) *reinterpret_cast<float4*>(out + (base + u * rpb + rin) * d + 4 * cv) = v[u];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pair_mul_rows4_kernel(const float* __restrict__ x, int64_t n, int64_t d, int dv,
+                                                                const int64_t* __restrict__ pos, int64_t P,
+                                                                float* __restrict__ h, int32_t* err_flag) {
+  const int cv = threadIdx.x % dv, rin = threadIdx.x / dv, rpb = kBlock / dv;
+  const int64_t step = static_cast<int64_t>(gridDim.x) * rpb * kRowsU;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * rpb * kRowsU; base < P; base += step) {
+    int64_t a[kRowsU], b[kRowsU];
+    bool ok[kRowsU];
+#pragma unroll
+    for (int u = 0; u < kRowsU; ++u) {
+      const int64_t i = base + u * rpb + rin, ic = i < P ? i : P - 1;
+      a[u] = pos[2 * ic];
+      b[u] = pos[2 * ic + 1];
+    }
+    float4 va[kRowsU], vb[kRowsU];
+#pragma unroll
+    for (int u = 0; u < kRowsU; ++u) {
+      const int64_t i = base + u * rpb + rin;
+      const bool in = a[u] >= 0 && a[u] < n && b[u] >= 0 && b[u] < n;
+      if (i < P && !in) flag_error(err_flag, LPG_F_INDEX_RANGE);
+      ok[u] = i < P && in;
+      va[u] = *reinterpret_cast<const float4*>(x + (in ? a[u] : 0) * d + 4 * cv);
+      vb[u] = *reinterpret_cast<const float4*>(x + (in ? b[u] : 0) * d + 4 * cv);
+    }
+#pragma unroll
+    for (int u = 0; u < kRowsU; ++u)
+      if (ok[u])
+        *reinterpret_cast<float4*>(h + (base + u * rpb + rin) * d + 4 * cv) =
+            make_float4(va[u].x * vb[u].x, va[u].y * vb[u].y, va[u].z * vb[u].z, va[u].w * vb[u].w);
+  }
+}
+
+inline bool rows4_ok(int64_t d) { return d % 4 == 0 && d / 4 <= kBlock && kBlock % (d / 4) == 0; }
+
 // one wave per scored edge: lanes stride the channels, xor-shuffle tree (fixed order)
 __global__ __launch_bounds__(kBlock) void pair_readout_kernel(const float* __restrict__ h, int64_t P, int64_t d,
                                                               const int64_t* __restrict__ idx, int64_t B,
@@ -93,7 +159,10 @@ LPG_EXPORT int lpg_embedding_f32(const float* table, int64_t n_rows, int64_t d, 
   LPG_REQUIRE(n >= 0 && d >= 1 && n_rows >= 0, "embedding: bad sizes");
   if (n == 0) return LPG_OK;
   LPG_REQUIRE(table && idx && out, "embedding: null pointer");
-  if (d % 4 == 0 && al16(table) && al16(out))
+  if (rows4_ok(d) && al16(table) && al16(out) && n_rows > 0)
+    hipLaunchKernelGGL(embedding_rows4_kernel, dim3(grid_for(ceil_div(n * (d / 4), kRowsU))), dim3(kBlock), 0,
+                       as_stream(stream), table, n_rows, d, static_cast<int>(d / 4), idx, n, out, err_flag);
+  else if (d % 4 == 0 && al16(table) && al16(out))
     hipLaunchKernelGGL(embedding_kernel<4>, dim3(grid_for(n * d / 4)), dim3(kBlock), 0, as_stream(stream), table,
                        n_rows, d, idx, n, out, err_flag);
   else
@@ -107,7 +176,10 @@ LPG_EXPORT int lpg_pair_gather_mul_f32(const float* x, int64_t n, int64_t d, con
   LPG_REQUIRE(n >= 0 && d >= 1 && P >= 0, "pair_gather_mul: bad sizes");
   if (P == 0) return LPG_OK;
   LPG_REQUIRE(x && pos && h, "pair_gather_mul: null pointer");
-  if (d % 4 == 0 && al16(x) && al16(h))
+  if (rows4_ok(d) && al16(x) && al16(h) && n > 0)
+    hipLaunchKernelGGL(pair_mul_rows4_kernel, dim3(grid_for(ceil_div(P * (d / 4), kRowsU))), dim3(kBlock), 0,
+                       as_stream(stream), x, n, d, static_cast<int>(d / 4), pos, P, h, err_flag);
+  else if (d % 4 == 0 && al16(x) && al16(h))
     hipLaunchKernelGGL(pair_mul_kernel<4>, dim3(grid_for(P * d / 4)), dim3(kBlock), 0, as_stream(stream), x, n, d, pos,
                        P, h, err_flag);
   else
