@@ -159,6 +159,39 @@ __global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restric
   }
 }
 
+// Row-tiled apply for d = 4 * 2^k <= 1024: a thread keeps ONE column chunk -- its 12 shift / scale / bias values live in
+// registers for the whole launch -- and walks rows, four in flight: per float4 of x one load and one store, instead of
+// a 64-bit modulo and twelve 4-byte stats loads.
+constexpr int kApplyU = 4;
+__global__ __launch_bounds__(kBlock) void gn_apply_rows4_kernel(const float* __restrict__ x, int64_t n, int64_t d, int dv,
+                                                                const float* __restrict__ stats, int relu,
+                                                                const float* __restrict__ add_to,
+                                                                float* __restrict__ y) {
+  const int cv = threadIdx.x % dv, rin = threadIdx.x / dv, rpb = kBlock / dv;
+  const float4 sh = *reinterpret_cast<const float4*>(stats + 4 * cv);
+  const float4 sc = *reinterpret_cast<const float4*>(stats + d + 4 * cv);
+  const float4 bi = *reinterpret_cast<const float4*>(stats + 2 * d + 4 * cv);
+  const int64_t step = static_cast<int64_t>(gridDim.x) * rpb * kApplyU;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * rpb * kApplyU; base < n; base += step) {
+    float4 v[kApplyU], a[kApplyU];
+#pragma unroll
+    for (int u = 0; u < kApplyU; ++u) {
+      const int64_t i = base + u * rpb + rin, ic = i < n ? i : n - 1;
+      v[u] = *reinterpret_cast<const float4*>(x + ic * d + 4 * cv);
+      if (add_to) a[u] = *reinterpret_cast<const float4*>(add_to + ic * d + 4 * cv);
+    }
+#pragma unroll
+    for (int u = 0; u < kApplyU; ++u) {
+      const int64_t i = base + u * rpb + rin;
+      float4 o = make_float4((v[u].x - sh.x) * sc.x + bi.x, (v[u].y - sh.y) * sc.y + bi.y, (v[u].z - sh.z) * sc.z + bi.z,
+                             (v[u].w - sh.w) * sc.w + bi.w);
+      if (relu) o = make_float4(o.x > 0.f ? o.x : 0.f, o.y > 0.f ? o.y : 0.f, o.z > 0.f ? o.z : 0.f, o.w > 0.f ? o.w : 0.f);
+      if (add_to) o = make_float4(o.x + a[u].x, o.y + a[u].y, o.z + a[u].z, o.w + a[u].w);
+      if (i < n) *reinterpret_cast<float4*>(y + i * d + 4 * cv) = o;
+    }
+  }
+}
+
 // ---- small n (<= 8192 rows): the whole op in ONE launch ------------------------------------------------
 // GraphNorm statistics are per column, so column blocks are independent: a 1024-thread workgroup owns four
 // columns (one float4 per row) of ALL rows, keeps its rows in registers (thread t: rows t, t+1024, ...), sums
@@ -325,7 +358,10 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
                      mean_scale, eps, stats);
   const bool wide = d % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
                     (!add_to || reinterpret_cast<uintptr_t>(add_to) % 16 == 0);
-  if (wide)
+  if (wide && d / 4 <= kBlock && kBlock % (d / 4) == 0)
+    hipLaunchKernelGGL(gn_apply_rows4_kernel, dim3(grid_for(ceil_div(n * (d / 4), kApplyU))), dim3(kBlock), 0, st, x, n, d,
+                       static_cast<int>(d / 4), stats, relu, add_to, y);
+  else if (wide)
     hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(grid_for(n * d / 4)), dim3(kBlock), 0, st, x, n, d, stats, relu, add_to, y);
   else
     hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(grid_for(n * d)), dim3(kBlock), 0, st, x, n, d, stats, relu, add_to, y);
