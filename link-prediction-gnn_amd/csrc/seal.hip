@@ -623,7 +623,8 @@ __global__ __launch_bounds__(kBlock) void seal_features_kernel(const int32_t* __
 // P = emb W_1[T:] (one small matmul per (emb, W_1), |V| x 32).  So  H_1[g] = W_1[tag_g] + P[node_g]:  two 128-byte
 // gathers and an add per vertex instead of writing 544 B of X and reading it back through a GEMM
 // (features 0.46 ms + linear 0.22 ms -> 0.1 ms per 100 K candidates).  Same sum, different association.
-__global__ __launch_bounds__(kBlock) void seal_h1_tables_kernel(const int32_t* __restrict__ nodes,
+constexpr int kH1Block = 64;     // ONE wave per subgraph: 8 rows per step cover the typical subgraph (mean 15 vertices) in two
+__global__ __launch_bounds__(kH1Block) void seal_h1_tables_kernel(const int32_t* __restrict__ nodes,
                                                                const int64_t* __restrict__ node_off,
                                                                const int32_t* __restrict__ tags,
                                                                const int32_t* __restrict__ tag_map, int64_t tag_map_len,
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void seal_h1_tables_kernel(const int32_t* _
     const int64_t base = node_off[b];
     int n = static_cast<int>(node_off[b + 1] - base);
     if (n > MAXN) n = MAXN;
-    for (int i0 = wave * 8; i0 < n; i0 += (kBlock / 64) * 8) {
+    for (int i0 = wave * 8; i0 < n; i0 += (kH1Block / 64) * 8) {
       const int i = i0 + sub;
       const int ic = i < n ? i : n - 1;              // clamped: the duplicate is not stored
       int32_t tg = tags[b * MAXN + ic];
@@ -938,7 +939,7 @@ LPG_EXPORT int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   LPG_REQUIRE(al16(w1_tag) && al16(p_table) && al16(h1), "seal_h1_tables: tables and output must be 16-byte aligned");
   const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));   // a workgroup per subgraph (see lpg_seal_subgraphs)
-  hipLaunchKernelGGL(seal_h1_tables_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), nodes, node_off, tags, tag_map,
+  hipLaunchKernelGGL(seal_h1_tables_kernel, dim3(grid), dim3(kH1Block), 0, as_stream(stream), nodes, node_off, tags, tag_map,
                      tag_map_len, T, w1_tag, p_table, n_graph, B, h1, ldh, err_flag);
   return check_launch("seal_h1_tables");
 }
