@@ -339,11 +339,14 @@ int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_off, const 
  * [n_tags] = rank of every PRESENT tag among the present ones, -1 for the others -- the global tag compaction of
  * SEAL/config/subgraph.py:84-101 (ascending tags -> 0 .. T-1) from the presence bytes lpg_seal_subgraphs filled
  * (tag_present may be NULL: no map); head [4] = {total vertices, *err_flag, T, 0} for the caller's single host
- * read.  Workspace only for B > 2^18 (lpg_seal_batch_index_bytes). */
+ * read.  first (may be NULL; capacity ceil(B * 128 / window_rows) + 1 entries is always enough, the number written
+ * is ceil(total / window_rows) + 1) receives the row windows of lpg_seal_conv_windows in the same launch.
+ * Workspace only for B > 2^18 (lpg_seal_batch_index_bytes). */
 int64_t lpg_seal_batch_index_bytes(int64_t B);
 int lpg_seal_batch_index(const int32_t* n_nodes, int64_t B, int64_t* node_off, const uint8_t* tag_present,
                          int64_t n_tags, int32_t* tag_map, const int32_t* err_flag, int64_t* head,
-                         void* workspace, int64_t workspace_bytes, void* stream);
+                         int32_t* first, int64_t window_rows, void* workspace, int64_t workspace_bytes,
+                         void* stream);
 
 /* first[w], w = 0 .. n_windows (n_windows + 1 entries) for lpg_seal_conv_stack_f32: one launch instead of a
  * searchsorted / arange / clamp chain; window_rows <= 128. */

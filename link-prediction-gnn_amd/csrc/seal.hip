@@ -769,7 +769,8 @@ __global__ __launch_bounds__(kIdxBlock) void seal_batch_index_kernel(const int32
                                                                      const uint8_t* __restrict__ present, int K,
                                                                      int32_t* __restrict__ tag_map,
                                                                      const int32_t* __restrict__ err_flag,
-                                                                     int64_t* __restrict__ head) {
+                                                                     int64_t* __restrict__ head,
+                                                                     int32_t* __restrict__ first, int64_t win) {
   __shared__ int64_t wsum[kIdxBlock / 64];
   const int t = threadIdx.x;
   int64_t carry = 0;
@@ -801,6 +802,22 @@ __global__ __launch_bounds__(kIdxBlock) void seal_batch_index_kernel(const int32
       head[1] = err_flag ? err_flag[0] : 0;
       head[3] = 0;
       if (!present) head[2] = 0;
+    }
+    if (first) {
+      // the conv stack's row windows (lpg_seal_conv_windows): first[w] = the first subgraph whose first row is >= w * win,
+      // for w = 0 .. ceil(total / win); node_off was written by this workgroup (or before the launch)
+      __threadfence_block();
+      __syncthreads();
+      const int64_t nw = (carry + win - 1) / win;
+      for (int64_t w = t; w <= nw; w += kIdxBlock) {
+        const int64_t target = w * win;
+        int64_t lo = 0, hi = B + 1;
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (off[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        first[w] = static_cast<int32_t>(lo < B ? lo : B);
+      }
     }
   } else if (present) {
     // 16 presence bytes per thread: the whole DRNL tag range (16 258 entries) is ONE tile, one block scan
@@ -978,8 +995,10 @@ LPG_EXPORT int64_t lpg_seal_batch_index_bytes(int64_t B) {
 
 LPG_EXPORT int lpg_seal_batch_index(const int32_t* n_nodes, int64_t B, int64_t* node_off, const uint8_t* tag_present,
                                     int64_t n_tags, int32_t* tag_map, const int32_t* err_flag, int64_t* head,
-                                    void* workspace, int64_t workspace_bytes, void* stream) {
+                                    int32_t* first, int64_t window_rows, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
   LPG_REQUIRE(B >= 0 && n_tags >= 0 && n_tags < (int64_t(1) << 30), "seal_batch_index: bad sizes");
+  LPG_REQUIRE(!first || (window_rows >= 1 && B < (int64_t(1) << 31)), "seal_batch_index: bad window_rows");
   LPG_REQUIRE(node_off && head && (B == 0 || n_nodes) && (!tag_present || tag_map), "seal_batch_index: null pointer");
   hipStream_t st = as_stream(stream);
   const int one_block = B <= kIdxOneBlockMax;
@@ -994,6 +1013,6 @@ LPG_EXPORT int lpg_seal_batch_index(const int32_t* n_nodes, int64_t B, int64_t* 
                                     static_cast<size_t>(B), rocprim::plus<int64_t>(), st, false));
   }
   hipLaunchKernelGGL(seal_batch_index_kernel, dim3(tag_present ? 2 : 1), dim3(kIdxBlock), 0, st, n_nodes, B, node_off,
-                     one_block, tag_present, static_cast<int>(n_tags), tag_map, err_flag, head);
+                     one_block, tag_present, static_cast<int>(n_tags), tag_map, err_flag, head, first, window_rows);
   return lpg::check_launch("seal_batch_index");
 }

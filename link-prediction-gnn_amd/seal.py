@@ -100,6 +100,7 @@ class SubgraphBatch:
         self._tag_map = None
         self._head = None
         self._n_tags = None
+        self._first = None
 
     def _index(self):
         """node offsets, tag map and the head {total, error flag, distinct tags} in ONE launch (lpg_seal_batch_index)."""
@@ -115,9 +116,12 @@ class SubgraphBatch:
             n = self.n if self.n.is_contiguous() else self.n.contiguous()
             nbytes = _lib.check(lib.lpg_seal_batch_index_bytes(self.B), "seal_batch_index_bytes")
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+            # small batches are launch-bound: the conv stack's 128-row windows ride along (sizes <= 128 => at most B + 1
+            # of them; one workgroup searches them, so not for big batches -- 100 K pairs: +0.1 ms, measured)
+            self._first = torch.empty(self.B + 2, dtype=torch.int32, device=dev) if self.B <= 8192 else None
             _lib.check(lib.lpg_seal_batch_index(P(n), self.B, P(self._off), P(present), K, P(self._tag_map),
-                                                P(_ops.err_flag(dev)), P(self._head), P(ws), nbytes, _ops._stream()),
-                       "seal_batch_index")
+                                                P(_ops.err_flag(dev)), P(self._head), P(self._first), CONV_WINDOW,
+                                                P(ws), nbytes, _ops._stream()), "seal_batch_index")
             self._total = self._n_tags = None
 
     def _read_head(self):
@@ -148,10 +152,11 @@ class SubgraphBatch:
 
     def invalidate(self):
         """the sizes / tags were edited in place (capped pairs replayed): recompute the index on next use"""
-        self._off = self._total = self._tag_map = self._head = self._n_tags = None
+        self._off = self._total = self._tag_map = self._head = self._n_tags = self._first = None
 
 
 CAP_POLICY = {"report": 0, "device": 1}
+CONV_WINDOW = 128               # rows per workgroup window of the dense conv stack (csrc/seal_conv.hip)
 
 
 def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, replay_n=None, cap_policy="device",
@@ -433,11 +438,14 @@ def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None, head_k1=None):
             h1 = _ops.linear(x, weights[0], w_is_km=True)           # the one big matmul: X W_1
         total = h1.shape[0]                                          # (h1 given: first_layer_h1, X never built)
         off = batch.node_off()
-        win = int(os.environ.get("LPG_SEAL_CONV_WINDOW", "128"))    # rows per workgroup window (<= 128); A/B hook
+        win = int(os.environ.get("LPG_SEAL_CONV_WINDOW", str(CONV_WINDOW)))    # rows per workgroup window (<= 128); A/B hook
         n_win = -(-total // win)
-        first = torch.empty(n_win + 1, dtype=torch.int32, device=h1.device)
-        _lib.check(lib.lpg_seal_conv_windows(_ops._ptr(off), batch.B, n_win, win, _ops._ptr(first), _ops._stream()),
-                   "seal_conv_windows")
+        if win == CONV_WINDOW and batch._first is not None and total == batch.total():
+            first = batch._first                                     # computed with the node offsets (lpg_seal_batch_index)
+        else:
+            first = torch.empty(n_win + 1, dtype=torch.int32, device=h1.device)
+            _lib.check(lib.lpg_seal_conv_windows(_ops._ptr(off), batch.B, n_win, win, _ops._ptr(first), _ops._stream()),
+                       "seal_conv_windows")
         fuse = head_k1 is not None
         cat = None if fuse else torch.empty((total, 96), dtype=torch.float32, device=h1.device)
         a16 = torch.empty((total, 16), dtype=torch.float32, device=h1.device) if fuse else None

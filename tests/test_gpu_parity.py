@@ -878,6 +878,12 @@ def test_seal_batch_index(dev, B):
     tm, T = batch.tag_map()
     want = np.where(present != 0, np.cumsum(present.astype(np.int64)) - 1, -1)
     assert T == int(present.sum()) and np.array_equal(_np(tm), want)
+    if B <= 8192:                                              # small batches: the conv stack's 128-row windows ride along
+        nw = -(-int(n.sum()) // 128)
+        want_first = np.minimum(np.searchsorted(off, np.arange(nw + 1) * 128, side="left"), B)
+        assert np.array_equal(_np(batch._first[: nw + 1]), want_first)
+    else:
+        assert batch._first is None
     nomap = seal.SubgraphBatch(pairs, None, torch.from_numpy(n).to(dev), None, None, None, None)
     assert nomap.total() == int(n.sum()) and np.array_equal(_np(nomap.node_off()), off)
     ops.err_flag(dev)[0] = 4                                   # a flagged extraction surfaces with the head
