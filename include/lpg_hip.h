@@ -357,6 +357,11 @@ int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* first, int64
                             const float* w3, const float* w4, float* cat, int64_t ldc, float* key,
                             const float* head_k1, float* head_a16, void* stream);
 
+/* The DGCNN head's last dense layer and its softmax in one launch (SEAL/model/gnn.py:127-137): pre_y [B, 2] =
+ * h [B, H] @ w [H, 2] + bias [2] (w as TensorFlow stores it, input index major), score [B] = softmax(pre_y)[:, 1]. */
+int lpg_seal_logits_f32(const float* h, int64_t ldh, int64_t B, int64_t H, const float* w, const float* bias,
+                        float* pre_y, float* score, void* stream);
+
 /* ---------------------------------------------------------------- SEAL head
  * SortPooling [SEAL/model/gnn.py:82-91]: per subgraph b, order its n_b vertices by key (= Z_4[:,0])
  * descending, ties -> lower vertex index first (tf.nn.top_k), take the first k rows of z

@@ -730,6 +730,41 @@ __global__ __launch_bounds__(kBlock) void softmax2_kernel(const float* __restric
   }
 }
 
+// ---- the head's last layer and the softmax in one launch (SEAL/model/gnn.py:127-137): pre_y = h W + b with W [H, 2]
+// (TensorFlow's x @ W), score = softmax(pre_y)[1].  16 lanes per row, float4 pieces, xor-shuffle tree (fixed order).
+__global__ __launch_bounds__(kBlock) void seal_logits_kernel(const float* __restrict__ h, int64_t ldh, int64_t B, int H,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ pre_y, float* __restrict__ score) {
+  const int lane16 = threadIdx.x & 15;
+  const int64_t grp = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 4;
+  const int64_t ngrp = (static_cast<int64_t>(gridDim.x) * kBlock) >> 4;
+  for (int64_t b0 = grp; b0 < B + (ngrp - (B % ngrp)) % ngrp; b0 += ngrp) {   // whole waves stay in step for the shuffles
+    const bool on = b0 < B;
+    const int64_t b = on ? b0 : B - 1;
+    float y0 = 0.f, y1 = 0.f;
+    for (int c = 4 * lane16; c < H; c += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(h + b * ldh + c);
+      const float4 wa = *reinterpret_cast<const float4*>(w + 2 * c);          // (c, 0) (c, 1) (c+1, 0) (c+1, 1)
+      const float4 wb = *reinterpret_cast<const float4*>(w + 2 * c + 4);
+      y0 += v.x * wa.x + v.y * wa.z + v.z * wb.x + v.w * wb.z;
+      y1 += v.x * wa.y + v.y * wa.w + v.z * wb.y + v.w * wb.w;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      y0 += __shfl_xor(y0, o, 64);
+      y1 += __shfl_xor(y1, o, 64);
+    }
+    if (on && lane16 == 0) {
+      if (bias) { y0 += bias[0]; y1 += bias[1]; }
+      pre_y[2 * b] = y0;
+      pre_y[2 * b + 1] = y1;
+      const float m = fmaxf(y0, y1);
+      const float e0 = expf(y0 - m), e1 = expf(y1 - m);
+      score[b] = e1 / (e0 + e1);
+    }
+  }
+}
+
 // ---- batch index: node_off = exclusive scan of the subgraph sizes, the tag map = ranks of the present tags, and
 // one 4-word head {total vertices, error flag, distinct tags, 0} for the batch's single host read.  One launch, two
 // workgroups (a dozen tiny scan / elementwise launches before: 40 of the 210 us of fb-pages-food's structure stage).
@@ -1015,4 +1050,17 @@ LPG_EXPORT int lpg_seal_batch_index(const int32_t* n_nodes, int64_t B, int64_t* 
   hipLaunchKernelGGL(seal_batch_index_kernel, dim3(tag_present ? 2 : 1), dim3(kIdxBlock), 0, st, n_nodes, B, node_off,
                      one_block, tag_present, static_cast<int>(n_tags), tag_map, err_flag, head, first, window_rows);
   return lpg::check_launch("seal_batch_index");
+}
+
+LPG_EXPORT int lpg_seal_logits_f32(const float* h, int64_t ldh, int64_t B, int64_t H, const float* w, const float* bias,
+                                   float* pre_y, float* score, void* stream) {
+  LPG_REQUIRE(B >= 0 && H >= 4 && H % 4 == 0 && H < (int64_t(1) << 30) && ldh >= H && ldh % 4 == 0,
+              "seal_logits: needs H % 4 == 0 and ldh % 4 == 0");
+  if (B == 0) return LPG_OK;
+  LPG_REQUIRE(h && w && pre_y && score, "seal_logits: null pointer");
+  LPG_REQUIRE(reinterpret_cast<uintptr_t>(h) % 16 == 0 && reinterpret_cast<uintptr_t>(w) % 16 == 0,
+              "seal_logits: h and w must be 16-byte aligned");
+  hipLaunchKernelGGL(seal_logits_kernel, dim3(grid_for(B * 16)), dim3(kBlock), 0, as_stream(stream), h, ldh, B,
+                     static_cast<int>(H), w, bias, pre_y, score);
+  return lpg::check_launch("seal_logits");
 }

@@ -538,9 +538,16 @@ def head(z, key, node_off, hw, a_all=None):
     # dense layer is ONE linear map from the pooled [k, 16] block to the 128 dense units.  Its matrix is folded once
     # per set of weights; the [B*k, 32] convolution output (230 MB per 100 K subgraphs) is never formed.
     dense = _ops.linear(a, _folded_conv2_dense(hw, k), hw["bias_1"], w_is_km=True, act="relu")
-    pre_y = _ops.linear(dense, hw["weight_2"], hw["bias_2"], w_is_km=True)
     score = torch.empty(B, dtype=torch.float32, device=a.device)
-    _lib.check(lib.lpg_softmax2_pos_score_f32(_ops._ptr(pre_y), B, _ops._ptr(score), _ops._stream()), "softmax2")
+    w2 = _ops._c(hw["weight_2"], torch.float32)
+    if tuple(w2.shape) == (dense.shape[1], 2) and dense.shape[1] % 4 == 0 and dense.stride(0) % 4 == 0:
+        pre_y = torch.empty((B, 2), dtype=torch.float32, device=a.device)       # last layer + softmax: one launch
+        _lib.check(lib.lpg_seal_logits_f32(_ops._ptr(dense), dense.stride(0), B, dense.shape[1], _ops._ptr(w2),
+                                           _ops._ptr(_ops._c(hw["bias_2"], torch.float32)), _ops._ptr(pre_y),
+                                           _ops._ptr(score), _ops._stream()), "seal_logits")
+    else:
+        pre_y = _ops.linear(dense, hw["weight_2"], hw["bias_2"], w_is_km=True)
+        _lib.check(lib.lpg_softmax2_pos_score_f32(_ops._ptr(pre_y), B, _ops._ptr(score), _ops._stream()), "softmax2")
     _ops.maybe_check(a.device, "seal forward index")       # the one deferred check of the scoring forward
     return pre_y, score
 
