@@ -256,6 +256,14 @@ int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8
                          int64_t* out, void* workspace, int64_t workspace_bytes,
                          int64_t* count_host, void* stream);
 
+/* The same graph for ANY size: both directions of every pair become a 64-bit key row * n_nodes + col, the keys are
+ * radix-sorted over their significant bits and deduplicated (rocPRIM), and one kernel emits col (ascending, unique
+ * per row) and rowptr.  col capacity col_cap >= 2 * n_pairs; rowptr[n_nodes] = nnz stays on the device; out-of-range
+ * pairs are flagged and dropped.  No host sync. */
+int64_t lpg_seal_train_csr_bytes(int64_t n_pairs, int64_t n_nodes);
+int lpg_seal_train_csr(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, int64_t* rowptr, int32_t* col,
+                       int64_t col_cap, void* workspace, int64_t workspace_bytes, int32_t* err_flag, void* stream);
+
 /* The train-positive graph `A` / `G` of SEAL (SEAL/config/subgraph.py:27-31,70-72) for SMALL graphs
  * (n_nodes <= lpg_seal_train_csr_small_max_nodes() = 8192; fb-pages-food has 620): symmetric, neighbours ascending
  * and unique per row, self loops kept.  pairs [n_pairs, 2] int64 (the train positives); `bits` = scratch of

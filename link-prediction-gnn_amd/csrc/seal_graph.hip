@@ -4,6 +4,9 @@
 // unique's size) costs 0.2 ms of a 0.65 ms scoring call.  Here: an n x n bit matrix (50 KB at n = 620), three launches:
 //   set bits (u, v) and (v, u)  ->  row popcounts + exclusive scan in one workgroup  ->  rows emit their set bits.
 // Integer work, bit-exact against the sort-based route by construction (a set has no order to get wrong).
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+
 #include "lpg_common.hpp"
 
 namespace {
@@ -94,6 +97,80 @@ __global__ __launch_bounds__(kBlock) void tg_fill_kernel(const uint32_t* __restr
     }
   }
 }
+
+// ---- any size: both directions of every pair as a 64-bit key row * n + col, sorted, deduplicated ---------------------
+inline unsigned key_bits(int64_t n) {                       // bits of the largest key, n * n (the dropped sentinel)
+  unsigned b = 1;
+  const unsigned __int128 top = static_cast<unsigned __int128>(n) * static_cast<unsigned __int128>(n);
+  while ((static_cast<unsigned __int128>(1) << b) <= top && b < 64) ++b;
+  return b;
+}
+
+__global__ __launch_bounds__(kBlock) void tg_keys_kernel(const int64_t* __restrict__ pairs, int64_t P, int64_t n,
+                                                         uint64_t* __restrict__ keys, int32_t* err_flag) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < P; i += stride) {
+    const int64_t u = pairs[2 * i], v = pairs[2 * i + 1];
+    const bool ok = u >= 0 && u < n && v >= 0 && v < n;
+    if (!ok) flag_error(err_flag, LPG_F_INDEX_RANGE);
+    const uint64_t drop = static_cast<uint64_t>(n) * static_cast<uint64_t>(n);
+    keys[2 * i] = ok ? static_cast<uint64_t>(u) * n + v : drop;
+    keys[2 * i + 1] = ok ? static_cast<uint64_t>(v) * n + u : drop;
+  }
+}
+
+// unique sorted keys -> col and rowptr; thread k owns the rows in (row[k-1], row[k]] (as rowptr_from_sorted in
+// csr_build.hip); the count comes from the device (rocprim::unique), the dropped sentinel sorts last and is cut off
+__global__ __launch_bounds__(kBlock) void tg_emit_kernel(const uint64_t* __restrict__ uniq,
+                                                         const int64_t* __restrict__ count, int64_t n,
+                                                         int64_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                         int64_t col_cap) {
+  int64_t M = *count;
+  const uint64_t drop = static_cast<uint64_t>(n) * static_cast<uint64_t>(n);
+  if (M > 0 && uniq[M - 1] == drop) --M;
+  if (M > col_cap) M = col_cap;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; k <= M; k += stride) {
+    const int64_t a = k == 0 ? -1 : static_cast<int64_t>(uniq[k - 1] / static_cast<uint64_t>(n));
+    const int64_t b = k == M ? n : static_cast<int64_t>(uniq[k] / static_cast<uint64_t>(n));
+    for (int64_t r = a + 1; r <= b; ++r) rowptr[r] = k;
+    if (k < M) col[k] = static_cast<int32_t>(uniq[k] % static_cast<uint64_t>(n));
+  }
+}
+
+struct TgWs {
+  uint64_t* keys;
+  uint64_t* sorted;
+  uint64_t* uniq;
+  int64_t* count;
+  void* tmp;
+  size_t tmp_bytes;
+  int64_t total;
+};
+
+TgWs tg_carve(void* ws, int64_t P, int64_t n) {
+  TgWs w;
+  const int64_t M = 2 * (P > 0 ? P : 1);
+  char* p = static_cast<char*>(ws);
+  w.keys = reinterpret_cast<uint64_t*>(p);
+  p += align_up(M * 8, 256);
+  w.sorted = reinterpret_cast<uint64_t*>(p);
+  p += align_up(M * 8, 256);
+  w.uniq = reinterpret_cast<uint64_t*>(p);
+  p += align_up(M * 8, 256);
+  w.count = reinterpret_cast<int64_t*>(p);
+  p += 256;
+  w.tmp = p;
+  size_t a = 0, b = 0;
+  (void)rocprim::radix_sort_keys(nullptr, a, static_cast<uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr),
+                                 static_cast<size_t>(M), 0u, key_bits(n), hipStream_t(0), false);
+  (void)rocprim::unique(nullptr, b, static_cast<uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr),
+                        static_cast<int64_t*>(nullptr), static_cast<size_t>(M), rocprim::equal_to<uint64_t>(),
+                        hipStream_t(0), false);
+  w.tmp_bytes = a > b ? a : b;
+  w.total = (p - static_cast<char*>(ws)) + align_up(static_cast<int64_t>(w.tmp_bytes), 256);
+  return w;
+}
 }  // namespace
 
 LPG_EXPORT int64_t lpg_seal_train_csr_small_max_nodes(void) { return kMaxNodes; }
@@ -118,4 +195,35 @@ LPG_EXPORT int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, i
   hipLaunchKernelGGL(tg_fill_kernel, dim3(grid_for(static_cast<int64_t>(n) * 64)), dim3(kBlock), 0, st, b, n, words, rowptr,
                      col, col_cap);
   return check_launch("seal_train_csr_small");
+}
+
+LPG_EXPORT int64_t lpg_seal_train_csr_bytes(int64_t n_pairs, int64_t n_nodes) {
+  if (n_pairs < 0 || n_nodes < 1 || n_nodes >= (int64_t(1) << 31)) return LPG_E_INVALID;
+  return tg_carve(nullptr, n_pairs, n_nodes).total;
+}
+
+LPG_EXPORT int lpg_seal_train_csr(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, int64_t* rowptr, int32_t* col,
+                                  int64_t col_cap, void* workspace, int64_t workspace_bytes, int32_t* err_flag,
+                                  void* stream) {
+  LPG_REQUIRE(n_pairs >= 0 && n_pairs < (int64_t(1) << 30) && n_nodes >= 1 && n_nodes < (int64_t(1) << 31) && col_cap >= 0,
+              "seal_train_csr: bad sizes");
+  LPG_REQUIRE(rowptr && (col || col_cap == 0) && (pairs || n_pairs == 0), "seal_train_csr: null pointer");
+  TgWs w = tg_carve(workspace, n_pairs, n_nodes);
+  if (!workspace || workspace_bytes < w.total) {
+    set_error("seal_train_csr: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)w.total);
+    return LPG_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t M = 2 * n_pairs;
+  LPG_HIP(hipMemsetAsync(w.count, 0, 8, st));
+  if (M > 0) {
+    hipLaunchKernelGGL(tg_keys_kernel, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, pairs, n_pairs, n_nodes, w.keys, err_flag);
+    size_t tmp = w.tmp_bytes;
+    LPG_HIP(rocprim::radix_sort_keys(w.tmp, tmp, w.keys, w.sorted, static_cast<size_t>(M), 0u, key_bits(n_nodes), st, false));
+    tmp = w.tmp_bytes;
+    LPG_HIP(rocprim::unique(w.tmp, tmp, w.sorted, w.uniq, w.count, static_cast<size_t>(M), rocprim::equal_to<uint64_t>(),
+                            st, false));
+  }
+  hipLaunchKernelGGL(tg_emit_kernel, dim3(grid_for(M + 1)), dim3(kBlock), 0, st, w.uniq, w.count, n_nodes, rowptr, col, col_cap);
+  return check_launch("seal_train_csr");
 }

@@ -81,6 +81,20 @@ def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
                                                 _ops._ptr(_ops.err_flag(positive.device)), _ops._stream()),
                    "seal_train_csr_small")
         return TrainGraph(rowptr, col, n_nodes)      # (col's tail past rowptr[n] is unused capacity; hub matrix: n too small)
+    if positive.is_cuda:
+        # any size: sorted, deduplicated 64-bit keys (row * n + col) -> col / rowptr, no host sync (csrc/seal_graph.hip)
+        lib = _lib.load()
+        train_pos = train_pos.contiguous()
+        P = train_pos.shape[0]
+        dev = positive.device
+        rowptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=dev)
+        col = torch.empty(max(2 * P, 1), dtype=torch.int32, device=dev)
+        nbytes = _lib.check(lib.lpg_seal_train_csr_bytes(P, n_nodes), "seal_train_csr_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.lpg_seal_train_csr(_ops._ptr(train_pos), P, n_nodes, _ops._ptr(rowptr), _ops._ptr(col), col.numel(),
+                                          _ops._ptr(ws), nbytes, _ops._ptr(_ops.err_flag(dev)), _ops._stream()),
+                   "seal_train_csr")
+        return TrainGraph(rowptr, col, n_nodes).build_hub_matrix()
     u, v = train_pos[:, 0], train_pos[:, 1]
     keys = torch.unique(torch.cat([u * n_nodes + v, v * n_nodes + u]))       # sorted, deduplicated
     rows = torch.div(keys, n_nodes, rounding_mode="floor")

@@ -1498,6 +1498,36 @@ def test_zero_size_inputs_everywhere(dev):
     assert b.B == 0 and b.n.numel() == 0
 
 
+def test_seal_train_csr_any_size(dev):
+    """lpg_seal_train_csr (sorted, deduplicated 64-bit keys; graphs of > 8192 nodes) against scipy: duplicates, reversed
+    pairs, self loops, empty rows, a hub, the test-ratio cut; extraction on the result equals extraction on a graph
+    built from the scipy CSR; an out-of-range pair is flagged and dropped."""
+    import scipy.sparse as sp
+    from lpgnn_amd import seal, ops
+    rng = np.random.default_rng(14)
+    for n, p, ratio in [(9000, 40_000, 0.0), (300_000, 500_000, 0.1), (70_000, 1, 0.0), (20_000, 0, 0.0)]:
+        pos = rng.integers(0, n, size=(p, 2)).astype(np.int64)
+        if p > 100:
+            pos[:50] = pos[50:100][:, ::-1]                      # reversed duplicates
+            pos[100:120, 1] = pos[100:120, 0]                    # self loops
+            pos[200:2000, 0] = 7                                 # a hub
+        g = seal.build_train_csr(pos, n, test_ratio=ratio, device=dev)
+        train = pos[: len(pos) - int(len(pos) * ratio)]
+        a = sp.coo_matrix((np.ones(2 * len(train), dtype=np.int8),
+                           (np.concatenate([train[:, 0], train[:, 1]]), np.concatenate([train[:, 1], train[:, 0]]))),
+                          shape=(n, n)).tocsr()
+        a.sum_duplicates()
+        a.sort_indices()
+        rp, cl = _np(g.rowptr), _np(g.col)
+        assert np.array_equal(rp, a.indptr.astype(np.int64))
+        assert np.array_equal(cl[: rp[-1]], a.indices.astype(np.int32))
+    bad = np.array([[1, 2], [3, 20_000], [4, 5]], dtype=np.int64)      # (3, n) is out of range: flagged and dropped
+    g = seal.build_train_csr(bad, 20_000, test_ratio=0.0, device=dev)
+    assert int(g.rowptr[-1]) == 4 and _np(g.col)[:4].tolist() == [2, 1, 5, 4]
+    with pytest.raises(IndexError):
+        ops.raise_if_flagged(torch.device(dev))
+
+
 def test_seal_train_csr_small_matches_sort_route(dev, sl):
     """lpg_seal_train_csr_small (bit matrix, three launches) against the sort / unique route and against numpy, on
     fb-pages-food's train positives and on random pair lists with duplicates, self loops, reversed pairs, empty rows."""
