@@ -95,6 +95,8 @@ def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
                                           _ops._ptr(ws), nbytes, _ops._ptr(_ops.err_flag(dev)), _ops._stream()),
                    "seal_train_csr")
         return TrainGraph(rowptr, col, n_nodes).build_hub_matrix()
+    # CPU tensors only (tests/test_seal_host.py checks the hub matrix's host logic on them): the same CSR through torch;
+    # nothing downstream runs without a ROCm device (extract_subgraphs raises on CPU tensors)
     u, v = train_pos[:, 0], train_pos[:, 1]
     keys = torch.unique(torch.cat([u * n_nodes + v, v * n_nodes + u]))       # sorted, deduplicated
     rows = torch.div(keys, n_nodes, rounding_mode="floor")
