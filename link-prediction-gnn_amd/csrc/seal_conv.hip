@@ -270,8 +270,10 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
     // conflicts on 48 writes per thread -- set-up was a third of the kernel); the strided global reads hit in L1
     // (the window's rows are 16-32 KB and every line is used by all 32 features)
     const int R2 = ntiles * 16;                       // row pairs
+    const int rcp_nt = (65536 + ntiles - 1) / ntiles; // block-uniform
     for (int idx = tid; idx < R2 * 32; idx += kConvBlock) {
-      const int c = idx / R2, rp = idx - c * R2, row = 2 * rp;
+      // idx / R2 without a division per element: R2 = 16 ntiles, (idx >> 4) < 256, so the 16-bit reciprocal is exact
+      const int c = ((idx >> 4) * rcp_nt) >> 16, rp = idx - c * R2, row = 2 * rp;
       const float v0 = row < nrows ? h1[(r_lo + row) * ldh + c] : 0.f;
       const float v1 = row + 1 < nrows ? h1[(r_lo + row + 1) * ldh + c] : 0.f;
       uint32_t a0, a1, a2, b0, b1, b2;
