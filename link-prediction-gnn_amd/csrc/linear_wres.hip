@@ -501,7 +501,11 @@ int dispatch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float*
   int variant = env ? atoi(env) : -1;
   const int nt = m <= 32 ? 1 : (m <= 64 ? 2 : 4);
   const bool wide = sizeof(T) == 4 && k > 16 * GK && k <= 20 * GK && nt <= 2;   // SEAL's [onehot || 128-d] rows
-  if (variant == 0 || n < 16384 || (k > 16 * GK && !wide) || m > 65535 * 32) return 0;
+  // persistent W-resident kernels pay off once every CU has several row tiles: from 16 K rows for narrow outputs, from
+  // 48 K for fp32 128-wide ones (k = m = 128: 25 vs 17 us at n = 16 K, 26 vs 18 at 32 K, equal at 50 K;
+  // profiles/r01/linear_small_n.log)
+  const int64_t n_min = sizeof(T) == 4 && nt == 4 ? 49152 : 16384;
+  if (variant == 0 || n < n_min || (k > 16 * GK && !wide) || m > 65535 * 32) return 0;
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   // X is read as whole 16-byte pieces of a row: rows must start 16-byte aligned and the last piece of a
   // row must lie inside the allocation (elements >= k are masked in registers, never used)
