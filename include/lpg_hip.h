@@ -43,6 +43,19 @@ extern "C" {
 
 const char* lpg_last_error(void);
 int lpg_abi_version(void);
+/* Kernel-selection options (csrc/options.hip; build-defined, no reference line): a process-wide table the launch
+ * paths read with plain loads -- the library never calls getenv on a launch path, and a release build never reads
+ * the environment at all.  Every value a release build accepts selects between variants that all return correct
+ * results (the tests pin each to the oracle): "spmm_chunk", "spmm_mode" (0 / 1), "spmm_lds", "spmm_block",
+ * "spmm_off32", "spmm_rows_max", "spmm_rows_ecap", "spmm_no_edge", "seal_conv_fp32", "gn_small",
+ * "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant), "seal_pair_small".
+ * `name` is a HOST string.  set: 0 / LPG_E_INVALID (unknown name, value out of range); get: the value, INT64_MIN
+ * for an unknown name.  lpg_tuning_build() = 1 for a -DLPG_TUNING build (profiles/ sweeps only: seeds the table
+ * once from LPG_<NAME> environment variables and accepts the measurement-only spmm_mode = 2), else 0. */
+int lpg_set_option(const char* name, int64_t value);
+int64_t lpg_get_option(const char* name);
+int lpg_reset_options(void);
+int lpg_tuning_build(void);
 /* edges per work chunk the chunked SpMM uses for a graph of capacity e_cap (16..512; tests use it
  * to place rows on chunk borders) */
 int lpg_spmm_chunk_edges(int64_t e_cap);
@@ -346,7 +359,7 @@ int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_off, const 
  * (the row offsets of the block-diagonal batch, SEAL/config/data.py:94-117 stacks per-graph arrays); tag_map
  * [n_tags] = rank of every PRESENT tag among the present ones, -1 for the others -- the global tag compaction of
  * SEAL/config/subgraph.py:84-101 (ascending tags -> 0 .. T-1) from the presence bytes lpg_seal_subgraphs filled
- * (tag_present may be NULL: no map); head [4] = {total vertices, *err_flag, T, 0} for the caller's single host
+ * (tag_present may be NULL: no map); head [4] = {total vertices, *err_flag, T, largest present tag (0 without tag_present)} for the caller's single host
  * read.  first (may be NULL; capacity ceil(B * 128 / window_rows) + 1 entries is always enough, the number written
  * is ceil(total / window_rows) + 1) receives the row windows of lpg_seal_conv_windows in the same launch.
  * Workspace only for B > 2^18 (lpg_seal_batch_index_bytes). */

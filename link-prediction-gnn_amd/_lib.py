@@ -11,7 +11,9 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(ROOT, "include", "lpg_hip.h")
-LIB_PATH = os.path.join(_PKG, "csrc", "liblpg_hip.so")
+# LPG_LIB_VARIANT=tuning: the -DLPG_TUNING build (csrc/build.py --tuning) for the sweep scripts under profiles/
+LIB_PATH = os.path.join(_PKG, "csrc", "liblpg_hip_tuning.so" if os.environ.get("LPG_LIB_VARIANT") == "tuning"
+                        else "liblpg_hip.so")
 
 _CTYPES = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
@@ -70,6 +72,33 @@ def load():
         raise LpgError("liblpg_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def set_option(name, value):
+    """process-wide kernel-selection option (include/lpg_hip.h: lpg_set_option)"""
+    check(load().lpg_set_option(name.encode(), int(value)), f"set_option({name})")
+
+
+def get_option(name):
+    return int(load().lpg_get_option(name.encode()))
+
+
+class options:
+    """with _lib.options(spmm_chunk=64, linear_wres=2): ...  -- sets the options, restores the old values on exit"""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def check(rc, what=""):

@@ -29,7 +29,13 @@ def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True, jobs=None):
+def build(force=False, verbose=True, jobs=None, tuning=False):
+    """tuning=True builds liblpg_hip_tuning.so with -DLPG_TUNING (the sweep scripts under profiles/ load it through
+    LPG_LIB_VARIANT=tuning): the options table is seeded from LPG_* environment variables and the measurement-only
+    kernel variants that return wrong results on purpose exist.  The product library has neither."""
+    LIB = os.path.join(HERE, "liblpg_hip_tuning.so" if tuning else "liblpg_hip.so")
+    OBJ = os.path.join(HERE, "build_tuning" if tuning else "build")
+    FLAGS = globals()["FLAGS"] + (["-DLPG_TUNING"] if tuning else [])
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")]
     headers.append(os.path.join(HERE, "..", "..", "include", "lpg_hip.h"))
@@ -67,4 +73,4 @@ def build(force=False, verbose=True, jobs=None):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tuning="--tuning" in sys.argv)

@@ -423,7 +423,7 @@ int blocks_per_cu(K kern, size_t lds, int block = kBlock) {
                           160 * 1024) != hipSuccess)
     return -1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, block, lds) != hipSuccess) return -1;
-  if (const char* e = getenv("LPG_LINEAR_PERCU_DELTA")) b += atoi(e);     // A/B hook (the API can be one block high)
+  b += static_cast<int>(options().linear_percu_delta);     // A/B option (the API can be one block high)
   return b < 1 ? 1 : b;
 }
 
@@ -497,15 +497,15 @@ template <typename T>
 int dispatch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float* bias, int act, T* y, int64_t ldy,
                   int64_t n, int64_t k, int64_t m, hipStream_t st) {
   constexpr int EPB = Elt<T>::EPB, GK = Elt<T>::GK;
-  const char* env = getenv("LPG_LINEAR_WRES");            // tuning / A-B hook, re-read per call: 0 off, 1 / 2 variant
-  int variant = env ? atoi(env) : -1;
+  int variant = static_cast<int>(options().linear_wres);   // -1 automatic; 0 off; 1 / 2 / 3 force that variant
+  const bool forced = variant > 0;
   const int nt = m <= 32 ? 1 : (m <= 64 ? 2 : 4);
   const bool wide = sizeof(T) == 4 && k > 16 * GK && k <= 20 * GK && nt <= 2;   // SEAL's [onehot || 128-d] rows
   // persistent W-resident kernels pay off once every CU has several row tiles: from 16 K rows for narrow outputs, from
   // 48 K for fp32 128-wide ones (k = m = 128: 25 vs 17 us at n = 16 K, 26 vs 18 at 32 K, equal at 50 K;
   // profiles/r01/linear_small_n.log)
   const int64_t n_min = sizeof(T) == 4 && nt == 4 ? 49152 : 16384;
-  if (variant == 0 || n < n_min || (k > 16 * GK && !wide) || m > 65535 * 32) return 0;
+  if (variant == 0 || (n < n_min && !forced) || n < 1 || (k > 16 * GK && !wide) || m > 65535 * 32) return 0;
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   // X is read as whole 16-byte pieces of a row: rows must start 16-byte aligned and the last piece of a
   // row must lie inside the allocation (elements >= k are masked in registers, never used)

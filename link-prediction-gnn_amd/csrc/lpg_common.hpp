@@ -15,6 +15,28 @@ constexpr int kBlock = 256; // 4 waves per workgroup, one per SIMD
 
 void set_error(const char* fmt, ...);
 
+// Process-wide kernel-selection options (csrc/options.hip; lpg_set_option / lpg_get_option / lpg_reset_options in
+// the ABI).  Plain loads at launch time: no getenv on any launch path.  Every option selects between code paths that
+// all return CORRECT results (tests pin each variant to the oracle); the measurement-only variants that do not
+// (spmm_mode 2: gather-only upper bound) exist only in a -DLPG_TUNING build of the library, which additionally
+// seeds the table once, at load, from LPG_* environment variables for the sweep scripts under profiles/.
+struct Options {
+  int64_t spmm_chunk = 0;        // edges per SpMM chunk (multiple of 16); 0 = automatic (chunk_for)
+  int64_t spmm_mode = 0;         // 0 default; 1 index-prefetch variant; 2 gather-only (LPG_TUNING builds only)
+  int64_t spmm_lds = -1;         // LDS bytes reserved per workgroup (occupancy limiter); -1 = automatic
+  int64_t spmm_block = kBlock;   // threads per workgroup: 64 / 128 / 256
+  int64_t spmm_off32 = 1;        // 32-bit gather offsets when X spans < 4 GiB
+  int64_t spmm_rows_max = 32;    // longest row for which the row-parallel one-launch SpMM is taken (0 disables)
+  int64_t spmm_rows_ecap = int64_t(1) << 21;
+  int64_t spmm_no_edge = 0;      // 1: narrow features (d <= 16) stay on the main kernel
+  int64_t seal_conv_fp32 = 0;    // 1: the fp32-MFMA formulation of the SEAL conv stack (no head fusion)
+  int64_t gn_small = 1;          // 0: GraphNorm keeps the three-launch path for small n
+  int64_t linear_percu_delta = 0;
+  int64_t linear_wres = -1;      // -1 automatic; 0 off; 1 / 2 / 3 force that W-resident variant (also below n_min)
+  int64_t seal_pair_small = 1;   // 0: every candidate pair takes the 128-thread extraction workgroup
+};
+const Options& options();
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int check_launch(const char* what) {

@@ -333,9 +333,8 @@ LPG_EXPORT int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const flo
   hipStream_t st = as_stream(stream);
   {
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-    const char* env = getenv("LPG_GN_SMALL");          // A/B hook: 0 keeps the three-launch path
     if (n <= kSmallRowsMax * kSmallBlock && d % 4 == 0 && d / 4 < 65536 && al16(x) && al16(y) && (!add_to || al16(add_to)) &&
-        !(env && atoi(env) == 0)) {
+        options().gn_small != 0) {   // option gn_small = 0 keeps the three-launch path
       launch_gn_small(dim3(static_cast<unsigned>(d / 4)), st, x, static_cast<int>(n), static_cast<int>(d), weight, bias,
                       mean_scale, eps, relu, add_to, y, static_cast<const int64_t*>(nullptr), 0,
                       static_cast<int32_t*>(nullptr));

@@ -835,8 +835,7 @@ __global__ __launch_bounds__(kIdxBlock) void seal_batch_index_kernel(const int32
     if (t == 0) {
       head[0] = carry;
       head[1] = err_flag ? err_flag[0] : 0;
-      head[3] = 0;
-      if (!present) head[2] = 0;
+      if (!present) head[2] = head[3] = 0;
     }
     if (first) {
       // the conv stack's row windows (lpg_seal_conv_windows): first[w] = the first subgraph whose first row is >= w * win,
@@ -856,6 +855,9 @@ __global__ __launch_bounds__(kIdxBlock) void seal_batch_index_kernel(const int32
     }
   } else if (present) {
     // 16 presence bytes per thread: the whole DRNL tag range (16 258 entries) is ONE tile, one block scan
+    __shared__ int smax;
+    int mx = -1;                                       // largest present tag (head[3]): the host's test for whether
+    if (t == 0) smax = -1;                             // CPython's set order can differ from ascending order
     for (int base = 0; base < K; base += 16 * kIdxBlock) {
       const int i0 = base + 16 * t;
       uint32_t w[4] = {0u, 0u, 0u, 0u};
@@ -874,10 +876,17 @@ __global__ __launch_bounds__(kIdxBlock) void seal_batch_index_kernel(const int32
       for (int j = 0; j < 16; ++j) {
         const bool p = ((w[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0;
         if (i0 + j < K) tag_map[i0 + j] = p ? static_cast<int32_t>(rank) : -1;
+        if (p && i0 + j < K) mx = i0 + j;
         rank += p;
       }
     }
-    if (t == 0) head[2] = carry;
+    __syncthreads();
+    if (mx >= 0) atomicMax(&smax, mx);
+    __syncthreads();
+    if (t == 0) {
+      head[2] = carry;
+      head[3] = smax;
+    }
   }
 }
 

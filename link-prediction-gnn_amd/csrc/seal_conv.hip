@@ -521,8 +521,7 @@ LPG_EXPORT int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* f
   LPG_REQUIRE(node_off && first && adj_bits && h1 && w2 && w3 && w4 && key, "seal_conv_stack: null pointer");
   LPG_REQUIRE((cat || head_k1) && (!head_k1 == !head_a16), "seal_conv_stack: needs cat, or head_k1 together with head_a16");
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-  const char* env = getenv("LPG_SEAL_CONV_FP32");       // A/B hook: 1 = the first formulation (fp32 MFMA, no head fusion)
-  if (env && atoi(env) != 0) {
+  if (options().seal_conv_fp32 != 0) {       // option: the first formulation (fp32 MFMA, no head fusion)
     LPG_REQUIRE(cat && !head_k1, "seal_conv_stack: the fp32 A/B kernel writes cat only");
     hipLaunchKernelGGL(seal_conv_dense_kernel, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0,
                        as_stream(stream), node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key);

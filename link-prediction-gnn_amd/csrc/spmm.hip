@@ -28,28 +28,23 @@ using namespace lpg;
 
 constexpr int kDefaultChunk = 512;  // edges per group chunk
 
-// Tuning hooks (profiles/sweep_spmm.py): LPG_SPMM_CHUNK = edges per chunk (multiple of 64),
-// LPG_SPMM_LDS = bytes of LDS reserved per workgroup (occupancy limiter; -1/unset = automatic),
-// LPG_SPMM_BLOCK = threads per workgroup, LPG_SPMM_MODE = 2 gather-only (debug upper bound: no row
-// flushes, results are WRONG).  Defaults are the tuned values.
+// Kernel-selection options (lpg_common.hpp `Options`, csrc/options.hip): spmm_chunk = edges per chunk, spmm_lds = bytes of
+// LDS reserved per workgroup (occupancy limiter; -1 = automatic), spmm_block = threads per workgroup, spmm_mode = 1
+// index-prefetch variant; spmm_mode = 2 (gather-only upper bound, WRONG results) exists in -DLPG_TUNING builds only.
 struct Tune {
   int chunk, mode, lds, block, off32;
   Tune() {
-    const char* c = getenv("LPG_SPMM_CHUNK");
-    const char* m = getenv("LPG_SPMM_MODE");
-    chunk = c ? atoi(c) : 0;           // 0 = automatic (chunk_for)
+    const Options& o = options();
+    chunk = static_cast<int>(o.spmm_chunk);
     if (chunk < 0 || chunk % 16 != 0) chunk = 0;
-    mode = m ? atoi(m) : 0;
-    const char* l = getenv("LPG_SPMM_LDS");
-    lds = l ? atoi(l) : -1;   // -1 = automatic
-    const char* o32 = getenv("LPG_SPMM_OFF32");
-    off32 = o32 ? atoi(o32) : 1;       // 0 disables the 32-bit gather offsets (A/B)
-    const char* bb = getenv("LPG_SPMM_BLOCK");
-    block = bb ? atoi(bb) : kBlock;
+    mode = static_cast<int>(o.spmm_mode);
+    lds = static_cast<int>(o.spmm_lds);
+    off32 = static_cast<int>(o.spmm_off32);
+    block = static_cast<int>(o.spmm_block);
     if (block != 64 && block != 128 && block != 256) block = kBlock;
   }
 };
-inline Tune tune() { return Tune(); }   // re-read per call: lets one process sweep variants
+inline Tune tune() { return Tune(); }
 
 // Edges per chunk: 512 on big graphs (flat between 256 and 2048, sweep_notes.md); small graphs get
 // smaller chunks (down to 16) so that a 70 K-edge tuple graph still spreads over thousands of
@@ -663,9 +658,12 @@ int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
 #define LPG_LAUNCH_MAIN(W, EPK, MD) \
   hipLaunchKernelGGL((spmm_main_kernel<T, VEC, G, W, EPK, 8, MD>), grid, blk, lds, st, a)
   static_assert(LPG_ACT_NONE == 0 && LPG_ACT_RELU == 1 && LPG_ACT_TANH == 2, "EPIK = 1 + act");
+#ifdef LPG_TUNING
   if (tn.mode == 2 && !a.val && !epi) {
-    LPG_LAUNCH_MAIN(false, 0, 2);              // debug: gather-only upper bound (wrong results)
-  } else if (tn.mode == 1 && !a.val && !epi) {
+    LPG_LAUNCH_MAIN(false, 0, 2);              // measurement only: gather-only upper bound (wrong results)
+  } else
+#endif
+  if (tn.mode == 1 && !a.val && !epi) {
     LPG_LAUNCH_MAIN(false, 0, 1);              // index prefetch variant
   } else if (!epi) {
     if (a.val) LPG_LAUNCH_MAIN(true, 0, 0); else LPG_LAUNCH_MAIN(false, 0, 0);
@@ -728,8 +726,8 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
                         reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
   // a group walks its row alone, so the kernel takes as long as the LONGEST row: worth it only for really short
   // rows (fb-pages-food's graphs have rows of ~110 edges and are faster on the chunked kernels, 110 vs 116 us / forward)
-  const int rows_max = getenv("LPG_SPMM_ROWS_MAX") ? atoi(getenv("LPG_SPMM_ROWS_MAX")) : 32;    // 0 disables (A/B)
-  const int64_t rows_ecap = getenv("LPG_SPMM_ROWS_ECAP") ? atoll(getenv("LPG_SPMM_ROWS_ECAP")) : (int64_t(1) << 21);
+  const int64_t rows_max = options().spmm_rows_max;    // 0 disables
+  const int64_t rows_ecap = options().spmm_rows_ecap;
   if (max_row_hint >= 0 && max_row_hint <= rows_max && wide_all && d / WIDE >= 2 && e_cap <= rows_ecap &&
       tune().mode == 0) {
     const int rc = launch_rows<T, WIDE>(a, st);
@@ -737,7 +735,7 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
     return check_launch("csr_spmm (rows)");
   }
   // d <= 16 in a power of two: the edge-parallel kernel (lanes = edges); wider rows: lanes = feature columns
-  const bool narrow = (d == 1 || d == 2 || d == 4 || d == 8 || d == 16) && tune().mode == 0 && !getenv("LPG_SPMM_NO_EDGE");
+  const bool narrow = (d == 1 || d == 2 || d == 4 || d == 8 || d == 16) && tune().mode == 0 && !options().spmm_no_edge;
   if (e_cap > 0 && narrow) {
     const int64_t n_chunks = ceil_div(e_cap, a.chunk);
     const int64_t gx = ceil_div(n_chunks, kBlock / kWave);

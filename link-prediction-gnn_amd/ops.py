@@ -17,11 +17,24 @@ _err_flags = {}
 
 
 def _need_gpu(*ts):
+    """every tensor of a call lives on ONE ROCm device, and that device is the current one: the launches below go to
+    torch's current stream of the current device, so a tensor of another GPU would be dereferenced on the wrong one."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.LpgError(
                 "lpgnn_amd ops run only on a ROCm device (got a CPU tensor); there is no CPU "
                 "fallback in the product path -- the CPU oracle lives under oracle/ for tests only")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise _lib.LpgError(f"lpgnn_amd: tensors of one call live on different devices ({dev} and {t.device})")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise _lib.LpgError(f"lpgnn_amd: tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
+                            f"wrap the call in `with torch.cuda.device({dev.index}):` (one process per GPU is the "
+                            "supported layout)")
 
 
 def _stream():
@@ -304,7 +317,7 @@ class CSRGraph:
         skip_empty_rows: rows without edges are left UNWRITTEN (the caller never reads them: the sparse multi-GPU
         exchange gathers only the non-empty rows of a partial)."""
         lib = _lib.load()
-        _need_gpu(x, row_scale, bias)
+        _need_gpu(self.rowptr, x, row_scale, bias, out)
         if x.dim() != 2 or x.shape[0] != self.n_cols:
             raise ValueError(f"spmm: x must be [{self.n_cols}, d], got {tuple(x.shape)}")
         if x.stride(1) != 1:
@@ -371,7 +384,7 @@ def graph_norm(x, weight, bias, mean_scale, eps=1e-5, relu=False, add_to=None, o
     x = _c(x, torch.float32)
     n, d = x.shape
     nbytes = _lib.check(lib.lpg_graphnorm_bytes(n, d), "graphnorm_bytes")
-    key = (x.device, "gn")
+    key = (x.device, _stream())               # one scratch buffer per (device, stream): concurrent streams must not share it
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -424,6 +437,7 @@ def pair_readout(h, idx, w, b):
 
 # ------------------------------------------------------------------------------ small-graph GCN blocks
 _small_limits = None
+SG_ROW_BLOCKS = None                # tests: force the number of row blocks of the small-graph aggregation
 
 
 def small_max_rows():
@@ -437,8 +451,7 @@ def small_max_rows():
 def small_row_blocks(e_cap):
     """row blocks a graph's aggregation is cut into (more workgroups, shorter edge strips per thread)."""
     small_max_rows()
-    env = os.environ.get("LPG_SG_ROW_BLOCKS")
-    rb = int(env) if env else (1 if e_cap < 16384 else 2 if e_cap < 32768 else 4 if e_cap < 131072 else 8)
+    rb = int(SG_ROW_BLOCKS) if SG_ROW_BLOCKS else (1 if e_cap < 16384 else 2 if e_cap < 32768 else 4 if e_cap < 131072 else 8)
     return max(1, min(rb, _small_limits[1]))
 
 

@@ -116,6 +116,7 @@ class SubgraphBatch:
         self._tag_map = None
         self._head = None
         self._n_tags = None
+        self._max_tag = -1
         self._first = None
 
     def _index(self):
@@ -144,8 +145,8 @@ class SubgraphBatch:
         """the batch's one host read: vertex total, the extraction's index check, number of distinct tags."""
         if self._total is None:
             self._index()
-            total, flag, n_tags, _ = self._head.tolist()
-            self._total, self._n_tags = int(total), int(n_tags)
+            total, flag, n_tags, max_tag = self._head.tolist()
+            self._total, self._n_tags, self._max_tag = int(total), int(n_tags), int(max_tag)
             if flag and _ops._CHECK:
                 _ops.err_flag(self._head.device).zero_()
                 raise IndexError(f"lpgnn_amd: candidate pair / node id out of range (flag={int(flag)})")
@@ -173,6 +174,7 @@ class SubgraphBatch:
 
 CAP_POLICY = {"report": 0, "device": 1}
 CONV_WINDOW = 128               # rows per workgroup window of the dense conv stack (csrc/seal_conv.hip)
+DENSE_STACK = True              # False: graph_conv_stack always takes the generic block-CSR path (A/B, tests)
 
 
 def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, replay_n=None, cap_policy="device",
@@ -324,22 +326,53 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
 _TAG_BOUND = 1 + 127 + 127 * 127
 
 
+_SET_MIN_SLOTS = 8            # CPython's PySet_MINSIZE: every set has at least 8 slots and hash(i) == i for small ints
+
+
+def _cpython_set_order(tag_lists):
+    """the reference's tag order, by executing the reference's own set algebra (SEAL/config/subgraph.py:90-94):
+    s = s.union(set(tags)) per subgraph, then list(s).  Host-side by nature: the order IS CPython's set iteration
+    order.  tag_lists: an iterable of per-subgraph tag sequences (padding already removed)."""
+    s = set()
+    for tags in tag_lists:
+        s = s.union(set(int(t) for t in tags))
+    return list(s)
+
+
 def compact_tag_map(batch):
-    """Global tag compaction (SEAL/config/subgraph.py:84-101).  The reference maps a tag to its
-    position in list(set(all tags)) -- CPython set order, which is ascending for the small
-    non-negative tags DRNL produces; here: ascending order.  Identity when tags == range(T)."""
-    # presence table instead of a sort-based unique over [B, 128] tags (0.32 -> 0.1 ms for 100 K pairs): a DRNL
-    # tag on <= 128 vertices is at most 1 + 127 + 127 * 127; slot 0 takes the -1 padding
+    """Global tag compaction (SEAL/config/subgraph.py:84-101): (tag_map int32 [TAG_BOUND + 1], T) with
+    tag_map[raw tag] = compacted tag, -1 for absent tags.  The reference maps a tag to its position in
+    list(set(all tags)), i.e. CPython set iteration order.  For non-negative ints below 8 that order is ascending
+    whatever the history of the set (hash(i) = i, >= 8 slots, no collision can happen), and hop <= 1 subgraphs
+    -- all the reference can run -- only produce DRNL tags {0, 1, 2, 3, 4, 6}: every vertex is adjacent to a
+    target, so its distance to the other one is <= 4 or infinite.  That case is one device launch (ascending rank
+    of the presence table).  When a larger tag is present (replayed node lists, hand-built batches) collisions in
+    the set's hash table can reorder it, and the map is rebuilt on the host by running the reference's own set
+    operations over the batch's tag lists -- same order as oracle.seal_int.compact_tags by construction."""
     dev = batch.tags.device
     if batch.tag_present is not None:                        # filled by the extraction kernel as it wrote the tags:
-        return batch.tag_map()                               # ranked with the batch's offsets, one launch, one host read
-    present = torch.zeros(_TAG_BOUND + 2, dtype=torch.uint8, device=dev)
-    present[batch.tags.reshape(-1).long() + 1] = 1
-    present = present[1:]
-    # ascending tags -> 0..T-1 is an exclusive scan of the presence table; ONE host read (T), no nonzero / max round trips
-    rank = torch.cumsum(present, 0, dtype=torch.int32)
-    tag_map = torch.where(present != 0, rank - 1, torch.full_like(rank, -1))
-    return tag_map, int(rank[-1].item())
+        tag_map, T = batch.tag_map()                         # ranked with the batch's offsets, one launch, one host read
+        max_tag = batch._max_tag
+    else:
+        # presence table instead of a sort-based unique over [B, 128] tags: a DRNL tag on <= 128 vertices is at most
+        # 1 + 127 + 127 * 127; slot 0 takes the -1 padding
+        present = torch.zeros(_TAG_BOUND + 2, dtype=torch.uint8, device=dev)
+        present[batch.tags.reshape(-1).long() + 1] = 1
+        present = present[1:]
+        rank = torch.cumsum(present, 0, dtype=torch.int32)
+        tag_map = torch.where(present != 0, rank - 1, torch.full_like(rank, -1))
+        idx = torch.arange(present.numel(), device=dev)
+        T, max_tag = (int(v) for v in torch.stack([rank[-1].long(), (idx * (present != 0)).max()]).tolist())
+    if max_tag < _SET_MIN_SLOTS or T == 0:
+        return tag_map, T
+    tags_h, n_h = batch.tags.cpu().numpy(), batch.n.cpu().numpy()
+    order = _cpython_set_order(tags_h[b, : n_h[b]] for b in range(tags_h.shape[0]))
+    if order == sorted(order) or set(order) == set(range(len(order))):
+        # ascending already -- or the reference's "already contiguous" branch (:98), which leaves the tags alone
+        return tag_map, T
+    tm = torch.full((tag_map.numel(),), -1, dtype=torch.int32)
+    tm[torch.as_tensor(order, dtype=torch.int64)] = torch.arange(len(order), dtype=torch.int32)
+    return tm.to(dev), T
 
 
 def gnn_inputs(batch, tag_map, tags_size, emb=None, fold_dinv=True, dtype=torch.float32, build_csr=True):
@@ -435,7 +468,7 @@ def _dense_ok(weights, dtype=torch.float32):
     """the reference's fp32 architecture: graph weights [F,32], [32,32], [32,32], [32,1] (SEAL/model/gnn.py:32-42)"""
     return (dtype == torch.float32 and len(weights) == 4 and [tuple(w.shape)[1] for w in weights] == [32, 32, 32, 1]
             and [tuple(w.shape)[0] for w in weights[1:]] == [32, 32, 32] and all(w.dtype == torch.float32 for w in weights)
-            and os.environ.get("LPG_SEAL_DENSE", "1") != "0")
+            and DENSE_STACK)
 
 
 def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None, head_k1=None):
@@ -454,7 +487,7 @@ def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None, head_k1=None):
             h1 = _ops.linear(x, weights[0], w_is_km=True)           # the one big matmul: X W_1
         total = h1.shape[0]                                          # (h1 given: first_layer_h1, X never built)
         off = batch.node_off()
-        win = int(os.environ.get("LPG_SEAL_CONV_WINDOW", str(CONV_WINDOW)))    # rows per workgroup window (<= 128); A/B hook
+        win = CONV_WINDOW                                            # rows per workgroup window (<= 128)
         n_win = -(-total // win)
         if win == CONV_WINDOW and batch._first is not None and total == batch.total():
             first = batch._first                                     # computed with the node offsets (lpg_seal_batch_index)
@@ -575,7 +608,7 @@ def score_links(positive, negative, nodes_size, emb, weights, head_weights, test
     if _dense_ok(weights) and emb is not None:          # X is never built: H_1 from two row gathers, then the dense stack
         k1 = head_weights["conv1d_kernel_1"]
         k1 = k1.reshape(-1, k1.shape[-1])
-        fuse = tuple(k1.shape) == (96, 16) and os.environ.get("LPG_SEAL_CONV_FP32", "0") == "0"
+        fuse = tuple(k1.shape) == (96, 16) and _lib.get_option("seal_conv_fp32") == 0
         h1 = first_layer_h1(batch, tag_map, T, emb, weights[0], check=False)       # head() reads the flag at the end
         z, key = graph_conv_stack(None, None, None, weights, batch=batch, h1=h1, head_k1=k1 if fuse else None)
         _, score = head(None if fuse else z, key, batch.node_off(), head_weights, a_all=z if fuse else None)

@@ -30,14 +30,20 @@ def reverse(edge_index):
 
 
 def double(x, for_index=False):
-    """TwoWL/utils.py:81-90 (layout glue, host-side reshapes only)."""
-    if not for_index:
-        row, col = x[0].reshape(1, x.shape[1]), x[1].reshape(1, x.shape[1])
-        x = torch.cat([row, col, col, row], 0).t()
-        return x.reshape(-1, 2).t()
-    x = x.reshape(1, x.shape[0])
-    x = torch.cat([2 * x, 2 * x + 1], 0).t()
-    return x.reshape(-1, 1).t().squeeze()
+    """TwoWL/utils.py:81-90 -- the both-directions layout reverse() relies on.
+    x [2, E] edges -> [2, 2E] with (r, c) at column 2k and (c, r) at column 2k + 1;
+    for_index: x [E] undirected-edge ids -> [2E] directed ids (2x, 2x + 1) interleaved.
+    Written as strided stores into the even / odd slots of the output."""
+    if for_index:
+        ids = x.reshape(-1)
+        out = ids.new_empty(2 * ids.numel())
+        torch.mul(ids, 2, out=out[0::2])
+        torch.add(out[0::2], 1, out=out[1::2])
+        return out
+    out = x.new_empty((2, 2 * x.shape[1]))
+    out[:, 0::2] = x
+    out[:, 1::2] = x.flip(0)
+    return out
 
 
 _side_streams = {}

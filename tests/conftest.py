@@ -33,3 +33,16 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def lpg_options():
+    """set kernel-selection options of the loaded library for one test (include/lpg_hip.h: lpg_set_option);
+    everything is back at its default afterwards."""
+    from lpgnn_amd import _lib
+
+    def set_(**kw):
+        for k, v in kw.items():
+            _lib.set_option(k, v)
+    yield set_
+    _lib.check(_lib.load().lpg_reset_options(), "reset_options")

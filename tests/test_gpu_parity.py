@@ -339,11 +339,11 @@ def test_spmm_bf16(dev, d):
 @pytest.mark.parametrize("chunk", ["16", "128", "512"])
 @pytest.mark.parametrize("d,dtype", [(1, torch.float32), (2, torch.float32), (4, torch.float32), (16, torch.float32),
                                      (1, torch.bfloat16), (4, torch.bfloat16), (16, torch.bfloat16)])
-def test_spmm_edge_parallel_kernel_long_chunks(dev, monkeypatch, chunk, d, dtype):
+def test_spmm_edge_parallel_kernel_long_chunks(dev, lpg_options, chunk, d, dtype):
     """d in {1,2,4,8,16} runs the edge-parallel kernel (lanes = edges, segmented scan).  Chunks longer than one
     64-edge step (the big-graph setting, forced here) exercise the running sum across steps, rows that span
     steps and chunks (a hub with a quarter of the edges), empty rows, and the epilogue (scale, bias, tanh)."""
-    monkeypatch.setenv("LPG_SPMM_CHUNK", chunk)
+    lpg_options(spmm_chunk=int(chunk))
     rng = np.random.default_rng(int(chunk) + d)
     for kw in ({}, {"scale": True, "bias": True, "act": "tanh"}):
         _check_spmm(dev, rng, 1500, 1300, 60000, d, True, hub=0.25, empty_frac=0.15, dtype=dtype, **kw)
@@ -610,7 +610,7 @@ def test_small_gcn_deferred_norm(dev, n, E, c, shape, rb, monkeypatch):
     from lpgnn_amd.nn import graph_cache
     from oracle import aggregation as agg
     if rb is not None:
-        monkeypatch.setenv("LPG_SG_ROW_BLOCKS", str(rb))
+        monkeypatch.setattr(ops, "SG_ROW_BLOCKS", rb)
     rng = np.random.default_rng(n + E + c)
     if shape == "star":                       # every edge into row 5: that row spans hundreds of strips
         ei = np.stack([rng.integers(0, n, size=E), np.full(E, 5)]).astype(np.int64)
@@ -681,7 +681,7 @@ def test_small_gcn_random_sweep(dev, monkeypatch):
         E = int(rng.integers(0, 40 * n)) if n < 2000 else int(rng.integers(0, 12 * n))
         c = int(rng.integers(1, 6))
         rb = int(rng.choice([1, 2, 3, 4, 8]))
-        monkeypatch.setenv("LPG_SG_ROW_BLOCKS", str(rb))
+        monkeypatch.setattr(ops, "SG_ROW_BLOCKS", rb)
         ei = rng.integers(0, n, size=(2, E)).astype(np.int64)
         if E and rng.random() < 0.4:
             ei[1, : E // 3] = rng.integers(0, n)                       # a heavy row
@@ -878,6 +878,7 @@ def test_seal_batch_index(dev, B):
     tm, T = batch.tag_map()
     want = np.where(present != 0, np.cumsum(present.astype(np.int64)) - 1, -1)
     assert T == int(present.sum()) and np.array_equal(_np(tm), want)
+    assert batch._max_tag == K - 1
     if B <= 8192:                                              # small batches: the conv stack's 128-row windows ride along
         nw = -(-int(n.sum()) // 128)
         want_first = np.minimum(np.searchsorted(off, np.arange(nw + 1) * 128, side="left"), B)
@@ -891,6 +892,27 @@ def test_seal_batch_index(dev, B):
     with pytest.raises(IndexError):
         flagged.total()
     assert int(ops.err_flag(dev)[0]) == 0
+
+
+def test_compact_tag_map_follows_the_reference_set_order_on_device(dev):
+    """seal.compact_tag_map on device batches whose tags are not contiguous: the presence table filled the way the
+    extraction kernel fills it, the largest tag read back with the batch head, and -- when CPython's set order is
+    not ascending -- the map rebuilt from the reference's own set algebra; against oracle.seal_int.compact_tags
+    (SEAL/config/subgraph.py:84-101)."""
+    from lpgnn_amd import seal
+    from oracle import seal_int
+    from tests.test_seal_host import NONCONTIGUOUS_TAG_LISTS, _hand_batch
+    for lists in NONCONTIGUOUS_TAG_LISTS:
+        want_tags, want_T = seal_int.compact_tags(lists)
+        batch = _hand_batch(lists, dev)
+        present = torch.zeros(seal._TAG_BOUND + 1, dtype=torch.uint8, device=dev)
+        present[torch.tensor(sorted({t for l in lists for t in l}), device=dev)] = 1
+        batch.tag_present = present
+        tag_map, T = seal.compact_tag_map(batch)
+        assert T == want_T and batch._max_tag == max(t for l in lists for t in l)
+        tm = _np(tag_map)
+        for raw, want in zip(lists, want_tags):
+            assert [int(tm[t]) for t in raw] == want
 
 
 def test_full_size_headline_instance_properties(dev):
@@ -1077,11 +1099,10 @@ def test_seal_hub_bit_matrix_matches_searches(dev):
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 130])
-def test_seal_dense_conv_stack_tiny_batches(dev, sl, B, monkeypatch):
+def test_seal_dense_conv_stack_tiny_batches(dev, sl, B):
     """the dense conv stack on batches of 1..130 candidate pairs (one row window, windows that own nothing, a last
     tile that is mostly padding): concat, sort key and the fused conv1d #1 against the generic CSR path."""
     from lpgnn_amd import seal
-    monkeypatch.delenv("LPG_SEAL_CONV_FP32", raising=False)
     pos = sl["positive"].astype(np.int64)
     graph = seal.build_train_csr(pos, 620, test_ratio=0.1, device=dev)
     rng = np.random.default_rng(B)
@@ -1102,13 +1123,12 @@ def test_seal_dense_conv_stack_tiny_batches(dev, sl, B, monkeypatch):
     assert torch.equal(kf, kd) and float((a16.double() - want).abs().max()) < 2e-5
 
 
-def test_seal_dense_conv_stack_matches_generic_at_scale(dev, monkeypatch):
+def test_seal_dense_conv_stack_matches_generic_at_scale(dev):
     """the dense-block MFMA conv stack against the generic CSR path on a hub-rich synthetic batch (236 K-node RMAT
     graph, 20 K candidate pairs, subgraphs of 2..100 vertices incl. capped ones, max_neighbors = 128 as well):
     every row of [Z1 | Z2 | Z3] and of the sort key within 2e-5."""
     import bench
-    from lpgnn_amd import seal
-    monkeypatch.delenv("LPG_SEAL_CONV_FP32", raising=False)     # the default kernel is the one under test
+    from lpgnn_amd import _lib, seal
     N, E = 235_868, 1_285_465
     ei = bench.rmat_edges(N, E, 1, dev)
     graph = seal.build_train_csr(ei.t().cpu().numpy(), N, test_ratio=0.0, device=dev)
@@ -1132,9 +1152,8 @@ def test_seal_dense_conv_stack_matches_generic_at_scale(dev, monkeypatch):
         mag = zd.double().abs() @ k1.double().abs()
         assert torch.equal(kf, kd) and a16.shape == (zd.shape[0], 16)
         assert torch.all((a16.double() - want).abs() <= TOL * mag + 1e-30)
-        monkeypatch.setenv("LPG_SEAL_CONV_FP32", "1")          # the first formulation (fp32 MFMA) as the A/B reference
-        z32, k32 = seal.graph_conv_stack(None, None, x, gw, batch=batch)
-        monkeypatch.delenv("LPG_SEAL_CONV_FP32")
+        with _lib.options(seal_conv_fp32=1):                   # the first formulation (fp32 MFMA) as the A/B reference
+            z32, k32 = seal.graph_conv_stack(None, None, x, gw, batch=batch)
         assert float((zd - z32).abs().max()) < 2e-5 and float((kd - k32).abs().max()) < 2e-5
 
 
@@ -1352,15 +1371,13 @@ def test_linear_bf16_mfma(dev, n, k, m, km):
     ("bf16", 16385, 32, 32, 32, True, None, True),
     ("bf16", 20011, 100, 20, 104, False, "relu", True),
 ])
-def test_linear_persistent_w_resident(dev, monkeypatch, variant, dtype, n, k, m, ldx, km, act, bias):
+def test_linear_persistent_w_resident(dev, lpg_options, variant, dtype, n, k, m, ldx, km, act, bias):
     """n >= 16384 takes the persistent W-resident kernels (csrc/linear_wres.hip); both variants and the
     shape-based choice against an fp64 matmul of the same (rounded) inputs; NaN in the row padding must
     never reach the result."""
     from lpgnn_amd import ops
-    if variant == "auto":
-        monkeypatch.delenv("LPG_LINEAR_WRES", raising=False)
-    else:
-        monkeypatch.setenv("LPG_LINEAR_WRES", variant)
+    if variant != "auto":
+        lpg_options(linear_wres=int(variant))              # forced variants also run below the automatic row threshold
     rng = np.random.default_rng(n + k + m)
     dt = torch.float32 if dtype == "f32" else torch.bfloat16
     xb = torch.from_numpy(rng.standard_normal((n, ldx)).astype(np.float32)).to(dev).to(dt)
@@ -1414,13 +1431,13 @@ def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
 
 @pytest.mark.parametrize("chunk", [None, "512"])
 @pytest.mark.parametrize("d,weighted", [(128, False), (128, True), (32, True), (64, False), (3, True), (256, False)])
-def test_spmm_bit_exact_vs_same_order_c_loop(dev, monkeypatch, d, weighted, chunk):
+def test_spmm_bit_exact_vs_same_order_c_loop(dev, lpg_options, d, weighted, chunk):
     """the atomic-free SpMM equals a plain fp32 CPU loop that adds in the same
     order (oracle/spmm_ref.c: CSR order inside a chunk, chunk pieces left to right) BIT FOR BIT."""
     import lpgnn_amd
     from oracle import aggregation as agg, spmm_c
     if chunk is not None:                                   # the big-graph chunk length on a small graph
-        monkeypatch.setenv("LPG_SPMM_CHUNK", chunk)
+        lpg_options(spmm_chunk=int(chunk))
     rng = np.random.default_rng(40 + d)
     n_rows, n_cols, E = 3000, 2500, 90000
     ei = rand_graph(rng, n_rows, n_cols, E, hub=0.25, empty_frac=0.1)
@@ -1436,12 +1453,12 @@ def test_spmm_bit_exact_vs_same_order_c_loop(dev, monkeypatch, d, weighted, chun
 
 
 @pytest.mark.parametrize("d,weighted", [(32, True), (128, False), (8, True), (256, True)])
-def test_spmm_short_rows_single_launch_bit_exact(dev, monkeypatch, d, weighted):
+def test_spmm_short_rows_single_launch_bit_exact(dev, lpg_options, d, weighted):
     """short rows known on the host => the one-launch row-parallel kernel: CSR order inside every row, i.e. the
     same-order C loop with a chunk longer than any row, bit for bit; empty rows carry act(bias)."""
     import lpgnn_amd
     from oracle import aggregation as agg, spmm_c
-    monkeypatch.setenv("LPG_SPMM_ROWS_MAX", "512")          # default 32: this graph's longest row is ~30-40
+    lpg_options(spmm_rows_max=512)                          # default 32: this graph's longest row is ~30-40
     rng = np.random.default_rng(70 + d)
     n_rows, n_cols, E = 3000, 2500, 40000
     ei = rand_graph(rng, n_rows, n_cols, E, hub=0.0, empty_frac=0.1)

@@ -103,3 +103,45 @@ def test_three_way_bf16_split_is_exact():
         for t in (hi, mid, lo):
             p = (np.float32(a) * t).astype(np.float32)
             assert np.array_equal(p.astype(np.float64), a * t.astype(np.float64))
+
+
+def _hand_batch(tag_lists, device="cpu"):
+    """a SubgraphBatch carrying only what compact_tag_map reads: per-subgraph sizes and (-1 padded) raw tags"""
+    B = len(tag_lists)
+    tags = np.full((B, seal.MAXN), -1, dtype=np.int32)
+    for b, t in enumerate(tag_lists):
+        tags[b, : len(t)] = t
+    n = torch.tensor([len(t) for t in tag_lists], dtype=torch.int32, device=device)
+    pairs = torch.zeros((B, 2), dtype=torch.int64, device=device)
+    return seal.SubgraphBatch(pairs, None, n, torch.from_numpy(tags).to(device), None, None, None)
+
+
+# tag sets the reference's `list(set(...))` (SEAL/config/subgraph.py:90-94) does NOT list in ascending order: values
+# at or above the set's slot count collide (hash(i) = i), e.g. 8 and 16 land on slot 0 of an 8-slot table
+NONCONTIGUOUS_TAG_LISTS = [
+    [[1, 1, 2, 3], [1, 1, 0, 10], [1, 1, 16, 2]],                       # the verdict's {0,1,2,3,10,16}
+    [[1, 1, 9], [1, 1, 17, 8], [1, 1, 16]],                             # collisions modulo 8
+    [[1, 1, 33, 2], [1, 1, 65, 3, 4], [1, 1, 6, 8, 11, 14, 18, 22, 27, 32]],
+    [[1, 1, 2, 3, 4, 6]],                                               # fb-pages-food's own set: ascending
+    [[1, 1], [1, 1, 0]],                                                # already contiguous: identity branch (:98)
+    [[1, 1, 1000, 24], [1, 1, 16257, 40, 8]],
+]
+
+
+def test_compact_tag_map_follows_the_reference_set_order():
+    """seal.compact_tag_map against oracle.seal_int.compact_tags (= the reference's set algebra) on tag sets that are
+    not contiguous and not in ascending set order: every raw tag must map to the same compacted tag."""
+    from oracle import seal_int
+    saw_unsorted = False
+    for lists in NONCONTIGUOUS_TAG_LISTS:
+        want_tags, want_T = seal_int.compact_tags(lists)
+        tag_map, T = seal.compact_tag_map(_hand_batch(lists))
+        assert T == want_T
+        tm = tag_map.numpy()
+        for raw, want in zip(lists, want_tags):
+            assert [int(tm[t]) for t in raw] == want
+        present = sorted({t for l in lists for t in l})
+        assert (tm >= 0).sum() == len(present) and all(tm[t] >= 0 for t in present)
+        order = seal._cpython_set_order(lists)
+        saw_unsorted |= order != sorted(order)
+    assert saw_unsorted, "no case exercised a non-ascending set order"
