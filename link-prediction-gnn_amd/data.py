@@ -4,6 +4,7 @@ the hot path consumes.
     load_edges / random_split_edges / negative_sampling / do_edge_split   <-> TwoWL/utils.py:93-147,
                                                                               TwoWL/operators/datasets.py:154-206
     BaseGraph / dataset / load_dataset                                     <-> TwoWL/operators/datasets.py:9-151
+    seal_load_data                                                         <-> SEAL/config/data.py:10-32
 
 The split itself is host-side index shuffling in the reference (torch CPU RNG); it is restated with
 the same sequence of ``torch.randperm`` draws, so under ``torch.manual_seed(s)`` it reproduces the
@@ -25,6 +26,45 @@ def load_edges(path: str) -> torch.Tensor:
     """``src,dst`` per line, no header (TwoWL/operators/datasets.py:156-163) -> int64 [2, E]."""
     e = np.loadtxt(path, delimiter=",", dtype=np.int64).reshape(-1, 2)
     return torch.from_numpy(e.T.copy())
+
+
+def seal_load_data(path: str, network_type: int = 0, seed: Optional[int] = 0):
+    """SEAL/config/data.py:10-32 -- the SEAL pipeline's candidate loader: (positive [P, 2], negative [P, 2], n_nodes).
+
+    * positives: the edge file read the way ``pd.read_csv(path, delimiter=',', dtype=int)`` reads it, i.e. with the
+      FIRST line taken as the column header (:17) -- fb-pages-food's 2102 lines give 2101 positives;
+    * negatives: ``list(nx.non_edges(G))`` shuffled, the first P kept (:21-26).  networkx enumerates the non-edges by
+      popping nodes from a Python set; the list is SORTED here before the shuffle, exactly as
+      tests/golden/make_golden.py does when it runs the reference, so that the result does not depend on set iteration
+      order (for ids below the set's slot count the reference's own order is already this one): pairs (u, v) with
+      u < v that are not adjacent (undirected), or every ordered pair u != v with no edge u -> v (directed);
+    * the two ``np.random.shuffle`` calls (negatives first, then positives, :24,27) are drawn from
+      ``np.random.RandomState(seed)`` -- the stream ``np.random.seed(seed)`` gives the reference; seed=None uses the
+      global numpy RNG like the reference itself;
+    * 1-based ids are shifted to 0-based (:29-31).  n_nodes = number of distinct node ids (``len(G.nodes())``).
+    Pinned by tests/golden/seal_int.npz ``positive`` / ``negative`` (reference-generated, seed 0)."""
+    positive = np.loadtxt(path, delimiter=",", dtype=np.int64, skiprows=1).reshape(-1, 2)
+    nodes = np.unique(positive)
+    n = nodes.size
+    rank = np.searchsorted(nodes, positive)                       # ids -> 0..n-1 positions (identity for 0..n-1 files)
+    adj = np.zeros((n, n), dtype=bool)
+    adj[rank[:, 0], rank[:, 1]] = True
+    if network_type == 0:
+        adj |= adj.T
+        free = np.triu(~adj, k=1)                                 # u < v, not adjacent (self pairs never listed)
+    else:
+        free = ~adj
+        np.fill_diagonal(free, False)                             # non_neighbors excludes the node itself
+    cu, cv = np.nonzero(free)                                     # row-major == sorted lexicographically
+    negative_all = np.stack([nodes[cu], nodes[cv]], axis=1)
+    rng = np.random.RandomState(seed) if seed is not None else np.random
+    rng.shuffle(negative_all)
+    negative = negative_all[: len(positive)].copy()
+    rng.shuffle(positive)
+    if positive.size and positive.min() == 1:
+        positive -= 1
+        negative -= 1
+    return positive, negative, int(n)
 
 
 def random_split_edges(edge_index: torch.Tensor, num_nodes: int, val_ratio: float = 0.05,

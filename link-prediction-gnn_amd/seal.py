@@ -617,3 +617,17 @@ def score_links(positive, negative, nodes_size, emb, weights, head_weights, test
     z, key = graph_conv_stack(g, d_inv, x, weights, batch=batch)
     _, score = head(z, key, batch.node_off(), head_weights)
     return score, labels, batch
+
+
+def score_links_from_file(path, emb, weights, head_weights, network_type=0, test_ratio=0.1, hop=1, seed=0, device="cuda"):
+    """edge file -> scores: the candidate loader of SEAL/config/data.py:10-32 (data.seal_load_data: header row eaten,
+    sorted non-edges shuffled under `seed`, positives shuffled) followed by the scoring forward above -- the
+    reference's `execute()` (SEAL/operators/seal_link_predict.py) from load_data to the per-candidate P(link), minus
+    training.  emb: [n_nodes, dim] node embedding (the reference trains node2vec for it; any table of that shape).
+    Returns (scores [2P], labels [2P, 1], batch, (positive, negative, n_nodes))."""
+    from . import data as _data
+    positive, negative, n_nodes = _data.seal_load_data(path, network_type, seed)
+    if emb is not None and emb.shape[0] != n_nodes:
+        raise ValueError(f"score_links_from_file: emb has {emb.shape[0]} rows, the edge file has {n_nodes} nodes")
+    score, labels, batch = score_links(positive, negative, n_nodes, emb, weights, head_weights, test_ratio, hop, device)
+    return score, labels, batch, (positive, negative, n_nodes)

@@ -35,3 +35,19 @@ def test_negative_sampling_contract():
     g2 = torch.Generator().manual_seed(3)
     torch.randint(0, n, (2, 400), generator=g2)
     assert torch.equal(data.negative_sampling(ei, n, 300, generator=g2), neg)      # seeded => reproducible
+
+
+def test_seal_load_data_matches_reference(golden_dir):
+    """data.seal_load_data against the candidate pairs the REFERENCE's own statements produced
+    (tests/golden/make_golden.py runs SEAL/config/data.py:17-27 under np.random.seed(0), non-edges sorted):
+    2101 positives (header row eaten), 2101 negatives, 620 nodes -- value for value, in order."""
+    sl = np.load(os.path.join(golden_dir, "seal_int.npz"))
+    pos, neg, n = data.seal_load_data(os.path.join(golden_dir, "fb-pages-food.edges"), network_type=0, seed=0)
+    assert n == int(sl["n_nodes"]) == 620 and pos.shape == neg.shape == (2101, 2)
+    assert np.array_equal(pos, sl["positive"]) and np.array_equal(neg, sl["negative"])
+    have = {(min(a, b), max(a, b)) for a, b in pos.tolist()}
+    assert all(a < b and (a, b) not in have for a, b in neg.tolist())
+    # directed: ordered pairs, no edge u -> v, never u == v
+    posd, negd, nd = data.seal_load_data(os.path.join(golden_dir, "fb-pages-food.edges"), network_type=1, seed=0)
+    haved = set(map(tuple, posd.tolist()))
+    assert nd == 620 and all(a != b and (a, b) not in haved for a, b in negd.tolist())

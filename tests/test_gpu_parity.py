@@ -1197,6 +1197,12 @@ def test_seal_head_with_reference_weights(dev, sl, golden_dir):
     assert torch.equal(s2, score)
     y = _np(lab).reshape(-1)
     assert 0.0 <= agg.auc(y, _np(s2)) <= 1.0
+    # edge file -> scores (SEAL/config/data.py:10-32 + the forward): the loader reproduces the golden candidates, so
+    # the scores must be the very same tensor
+    s3, lab3, _, (p3, n3, nn3) = seal.score_links_from_file(os.path.join(golden_dir, "fb-pages-food.edges"), emb, gw, hw,
+                                                            seed=0, device=dev)
+    assert nn3 == 620 and np.array_equal(p3, pos) and np.array_equal(n3, neg)
+    assert torch.equal(s3, score) and torch.equal(lab3, lab)
 
 
 def test_seal_capped_pairs_device_policy(dev, sl):
