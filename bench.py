@@ -9,7 +9,8 @@ kernels of lpg_csr_spmm_f32) with graph, plan and X already resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the north star's
+N > 1 (one rank per GPU over RCCL; started by torch.distributed.run, or by this script itself as a child process
+when it is run plainly with --gpus N): the north star's
 source-edge partition -- rank g owns source rows [g*V/N, (g+1)*V/N) of X and the |E| = 100 M
 edges that leave them (weak scaling: per-GPU edges fixed), computes a partial Y_g[V, d], and the
 partials are summed over xGMI so that every rank keeps the rows of its own range (what the next layer on
@@ -168,7 +169,7 @@ def twowl_forward_bench(device, iters=50):
     return {"workload": "fb-pages-food TwoWL test-split scoring forward fp32 (configs[1]): N=620 E1=3480 P=4252 "
                         "E2=69525 B=386, C1=256 C2=32 depth 1/1", "scored_edges": y_len // 2,
             "us_per_forward": dt * 1e6, "scored_edges_per_s": (y_len // 2) / dt,
-            "us_per_forward_eager": dt_eager * 1e6, "mode": "hipGraph replay of the whole forward",
+            "us_per_forward_eager": dt_eager * 1e6, "scored_edges_per_s_eager": (y_len // 2) / dt_eager, "mode": "hipGraph replay of the whole forward",
             "reference_recorded_s_per_forward": [0.0698, 0.1361]}
 
 
@@ -300,6 +301,73 @@ def combine_over_ranks(result, world, rank, timeout_s=180):
     return out
 
 
+def launch_ranks(n):
+    """start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` as a child
+    process (one rank per GPU over RCCL; with LPG_BENCH_BACKEND=gloo every rank shares GPU 0: rehearsal of the N > 1
+    logic on a one-GPU box) and return its exit code.  Called before anything initialises the GPU."""
+    import socket
+    import subprocess
+    if os.environ.get("LPG_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:   # counting does not initialise HIP
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {torch.cuda.device_count()} "
+              "(LPG_BENCH_BACKEND=gloo rehearses the N > 1 path on one GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def spmm_compulsory_bytes(n_rows, n_cols, n_edges, d, elt=4, weighted=False):
+    """SURVEY.md section 8d's compulsory lower bound: every index once, every X row once, every Y row once:
+    E*b_idx (+ E*4 weighted) + (N+1)*8 + (n_cols + n_rows)*d*s."""
+    return n_edges * (4 + (4 if weighted else 0)) + (n_rows + 1) * 8 + (n_cols + n_rows) * d * elt
+
+
+def file_sha256(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def profiled_traffic(N, E, d, dtype):
+    """(hbm bytes per step from the committed rocprofv3 --pmc passes, source string) -- only when the counter file was
+    collected for THIS workload with THIS spmm.hip (sha256 recorded in the file); otherwise (None, why)."""
+    tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(tj):
+        return None, "no profiles/traffic_latest.json"
+    try:
+        tr = json.load(open(tj))
+    except Exception as e:          # noqa: BLE001
+        return None, f"profiles/traffic_latest.json unreadable: {e!r}"
+    if tr.get("workload") != [N, E, d, dtype]:
+        return None, "profiles/traffic_latest.json is for another workload"
+    sha = file_sha256(os.path.join(ROOT, "link-prediction-gnn_amd", "csrc", "spmm.hip"))
+    if tr.get("spmm_hip_sha256") != sha:
+        return None, "profiles/traffic_latest.json is stale: collected with another csrc/spmm.hip"
+    return tr.get("hbm_bytes_per_step"), (f"profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                          f"{tr.get('collected', '?')}, spmm.hip sha256 {sha[:12]}; not collected in this run)")
+
+
+def spmm_phase_split(g, x, iters=5):
+    """per-kernel split of one step from events the library records around its own kernels (lpg_csr_spmm_phase_ms)"""
+    import ctypes
+    from lpgnn_amd import _lib
+    out = (ctypes.c_float * 3)()
+    acc = [0.0, 0.0, 0.0]
+    with _lib.options(spmm_phase_timing=1):
+        for _ in range(iters):
+            g.spmm(x)
+            _lib.check(_lib.load().lpg_csr_spmm_phase_ms(ctypes.addressof(out)), "csr_spmm_phase_ms")
+            for i in range(3):
+                acc[i] += out[i] / iters
+    return {"spmm_main_kernel_ms": acc[0], "spmm_fixup_kernel_ms": acc[1], "spmm_empty_rows_kernel_ms": acc[2]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,12 +390,17 @@ def main():
     ap.add_argument("--no-twowl", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the ranks ourselves.  This process has not touched the GPU (no
+        # torch.cuda call so far) and never will: the ranks are CHILD processes of torch.distributed.run, whose
+        # stdout / stderr / return code are relayed.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "(python bench.py --gpus N does it by itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
     if os.environ.get("LPG_BENCH_BACKEND", "nccl") != "nccl":
@@ -382,19 +455,30 @@ def main():
         if runner.collective == "sparse":
             # self-check before anything is timed: the sparse exchange must reproduce the dense reduce-scatter on this
             # very graph, on every rank; if not (or if it raises), every rank falls back to the reduce-scatter
+            # Two phases, so that no rank can skip a collective its peers have entered: (1) everything that can fail
+            # LOCALLY (the packed stage SpMMs, the buffers of both forms) runs first and the ranks agree on the outcome
+            # with one all_reduce(MIN) that every rank reaches; (2) only then the two exchanges run, outside any
+            # try/except -- an error inside a collective is fatal for the job (the launcher ends every rank), never
+            # a silent hang -- and a second agreement compares the results.
             ok = 1
             try:
-                ya = runner.forward(x)
-                yb = runner.forward(x, collective="reduce_scatter")
-                tol = 1e-4 * float(yb.abs().max()) + 1e-6 if dtype == torch.float32 else 2e-2 * float(yb.abs().max()) + 1e-3
-                ok = int(float((ya - yb).abs().max()) <= tol)
-                del ya, yb
-            except Exception as exc:                      # noqa: BLE001 -- any failure means "do not use it"
-                print(f"[bench] rank {rank}: sparse exchange failed its self-check: {exc!r}", file=sys.stderr, flush=True)
+                runner.compute_only(x)
+                runner.preallocate(x)
+                torch.cuda.synchronize()
+            except Exception as exc:                      # noqa: BLE001 -- any local failure means "do not use it"
+                print(f"[bench] rank {rank}: sparse exchange failed its local check: {exc!r}", file=sys.stderr, flush=True)
                 ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
             if dist is not None:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                ya = runner.forward(x)
+                yb = runner.forward(x, collective="reduce_scatter")
+                tol = 1e-4 * float(yb.abs().max()) + 1e-6 if dtype == torch.float32 else 2e-2 * float(yb.abs().max()) + 1e-3
+                flag[0] = int(float((ya - yb).abs().max()) <= tol)
+                del ya, yb
+                if dist is not None:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 runner.collective = "reduce_scatter"
             elif args.collective == "auto":
@@ -445,6 +529,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    phase_ms = None
+    if runner is None and world == 1:
+        try:
+            phase_ms = spmm_phase_split(g, x)
+        except Exception as e:                   # noqa: BLE001 -- a diagnostic, never takes the headline down
+            phase_ms = {"error": repr(e)}
     per_step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     kern_ms = sum(per_step_ms) / len(per_step_ms)
     nnz = g.nnz() if g is not None else runner.nnz()
@@ -502,22 +592,22 @@ def main():
             out["seal_sharded"] = seal_sharded
         if runner_was_none and world == 1:
             alg = spmm_algorithmic_bytes(N, nnz, d, elt)
+            comp = spmm_compulsory_bytes(N, N, nnz, d, elt)
             ach = alg / (kern_ms * 1e-3) / 1e9
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tj):
-                try:
-                    tr = json.load(open(tj))
-                    if tr.get("workload") == [N, E, d, args.dtype]:
-                        traffic = tr.get("hbm_bytes_per_step")
-                except Exception:
-                    traffic = None
+            traffic, traffic_source = profiled_traffic(N, E, d, args.dtype)
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                "kernel": "lpg_csr_spmm (spmm_main_kernel + spmm_fixup_kernel + spmm_empty_rows_kernel, "
                                          "HIP-event time of the whole call on the launch stream)",
-                               "algorithmic_bytes_per_step": alg, "avg_launch_ms": kern_ms,
+                               "algorithmic_bytes_per_step": alg, "compulsory_bytes_per_step": comp,
+                               "avg_launch_ms": kern_ms,
+                               # the three fractions of SURVEY 8d, all against the 8 TB/s spec peak
+                               "frac_gather_model": ach / HBM_PEAK_GBS,
+                               "frac_compulsory_bound": comp / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "frac_counter_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                                "frac_of_measured_copy_ceiling_6290": ach / 6290.0}
+            if phase_ms is not None:
+                out["roofline"]["kernel_split_ms"] = phase_ms
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(d)
             if not args.no_twowl:
@@ -535,6 +625,12 @@ def main():
                                "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "rank 0: lpg_csr_spmm stages + the step's collective (HIP-event time of the whole step)",
                                "algorithmic_bytes_per_step": alg, "avg_launch_ms": kern_ms}
+        # BASELINE.json's metric counts SCORED edges: the model-level forwards' figures, next to the kernel-level headline
+        sc = {"seal_collab_100k": (out.get("seal_sharded") or {}).get("scored_edges_per_s"),
+              "seal_fb": (out.get("seal") or {}).get("scored_edges_per_s"),
+              "twowl_fb": (out.get("twowl") or {}).get("scored_edges_per_s"),
+              "twowl_fb_eager": (out.get("twowl") or {}).get("scored_edges_per_s_eager")}
+        out["scored_edges_per_s"] = {k: v for k, v in sc.items() if v is not None}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

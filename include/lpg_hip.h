@@ -48,7 +48,8 @@ int lpg_abi_version(void);
  * the environment at all.  Every value a release build accepts selects between variants that all return correct
  * results (the tests pin each to the oracle): "spmm_chunk", "spmm_mode" (0 / 1), "spmm_lds", "spmm_block",
  * "spmm_off32", "spmm_rows_max", "spmm_rows_ecap", "spmm_no_edge", "seal_conv_fp32", "gn_small",
- * "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant), "seal_pair_small".
+ * "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant), "seal_pair_small",
+ * "spmm_phase_timing" (1: lpg_csr_spmm_* record events around their kernels, see lpg_csr_spmm_phase_ms).
  * `name` is a HOST string.  set: 0 / LPG_E_INVALID (unknown name, value out of range); get: the value, INT64_MIN
  * for an unknown name.  lpg_tuning_build() = 1 for a -DLPG_TUNING build (profiles/ sweeps only: seeds the table
  * once from LPG_<NAME> environment variables and accepts the measurement-only spmm_mode = 2), else 0. */
@@ -152,6 +153,12 @@ int lpg_csr_spmm_bf16(const void* plan, const int64_t* rowptr, const int32_t* co
                       int64_t N, int64_t n_cols, int64_t e_cap, int64_t d, const float* row_scale,
                       const float* bias, int act, int64_t n_empty_hint, int64_t max_row_hint,
                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Per-kernel split of the most recent lpg_csr_spmm_* call made with option "spmm_phase_timing" = 1: out_ms (HOST,
+ * 3 floats) = {main kernel, fix-up kernel, empty-rows kernel} in milliseconds, from events the library recorded on
+ * the launch stream.  Syncs on the last of them.  bench.py reports it next to the whole-call HIP-event time so the
+ * rocprofv3 kernel statistics under profiles/ can be checked against the JSON line. */
+int lpg_csr_spmm_phase_ms(float* out_ms);
 
 /* ---------------------------------------------------------------- dense feature linear (K5)
  * Y[n,m] = X[n,k] @ W^T (+ bias), W is [m,k] (nn.Linear / GCNConv.lin layout) or, with

@@ -536,10 +536,14 @@ int dispatch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float*
 namespace lpg {
 int linear_wres_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, int act, float* y,
                     int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st) {
-  return dispatch_wres<float>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+  const int rc = dispatch_wres<float>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+  if (rc == 1) ++options_mut().stat_linear_wres;
+  return rc;
 }
 int linear_wres_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, int w_is_km, const float* bias, int act,
                      uint16_t* y, int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st) {
-  return dispatch_wres<uint16_t>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+  const int rc = dispatch_wres<uint16_t>(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+  if (rc == 1) ++options_mut().stat_linear_wres;
+  return rc;
 }
 }  // namespace lpg

@@ -33,9 +33,12 @@ struct Options {
   int64_t gn_small = 1;          // 0: GraphNorm keeps the three-launch path for small n
   int64_t linear_percu_delta = 0;
   int64_t linear_wres = -1;      // -1 automatic; 0 off; 1 / 2 / 3 force that W-resident variant (also below n_min)
+  int64_t spmm_phase_timing = 0; // 1: record events around the SpMM's kernels (lpg_csr_spmm_phase_ms)
   int64_t seal_pair_small = 1;   // 0: every candidate pair takes the 128-thread extraction workgroup
+  int64_t stat_linear_wres = 0;  // statistic: W-resident linear launches so far (tests assert the path taken; set 0 to reset)
 };
 const Options& options();
+Options& options_mut();
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -34,7 +34,9 @@ const Entry kEntries[] = {
     {"gn_small", &Options::gn_small, 0, 1},
     {"linear_percu_delta", &Options::linear_percu_delta, -8, 8},
     {"linear_wres", &Options::linear_wres, -1, 3},
+    {"spmm_phase_timing", &Options::spmm_phase_timing, 0, 1},
     {"seal_pair_small", &Options::seal_pair_small, 0, 1},
+    {"stat_linear_wres", &Options::stat_linear_wres, 0, int64_t(1) << 62},
 };
 
 Options g_options;
@@ -71,6 +73,7 @@ const Options& options() {
   }
   return g_options;
 }
+Options& options_mut() { return const_cast<Options&>(options()); }
 }  // namespace lpg
 
 LPG_EXPORT int lpg_set_option(const char* name, int64_t value) {

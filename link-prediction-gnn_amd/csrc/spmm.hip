@@ -60,6 +60,23 @@ inline int chunk_for(int64_t e_cap) {
   return c;
 }
 
+// Per-phase timing of one SpMM call (option spmm_phase_timing = 1; bench.py's per-kernel split of the step): four
+// library-owned events recorded on the launch stream around {main kernel | fix-up | empty rows}.  Results are not
+// affected; the records cost a few microseconds, so the option is off outside the measuring loop.
+hipEvent_t g_phase_ev[4];
+bool g_phase_ev_ready = false;
+bool g_phase_recorded = false;
+inline void phase_mark(int i, hipStream_t st) {
+  if (!options().spmm_phase_timing) return;
+  if (!g_phase_ev_ready) {
+    for (auto& e : g_phase_ev)
+      if (hipEventCreate(&e) != hipSuccess) return;
+    g_phase_ev_ready = true;
+  }
+  (void)hipEventRecord(g_phase_ev[i], st);
+  if (i == 3) g_phase_recorded = true;
+}
+
 struct SpmmArgs {
   const int64_t* rowptr;
   const int32_t* col;
@@ -675,6 +692,7 @@ int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
     if (a.val) LPG_LAUNCH_MAIN(true, 3, 0); else LPG_LAUNCH_MAIN(false, 3, 0);
   }
 #undef LPG_LAUNCH_MAIN
+  phase_mark(1, st);
   hipLaunchKernelGGL((spmm_fixup_kernel<T, VEC, G>), grid, blk, 0, st, a);
   return LPG_OK;
 }
@@ -734,6 +752,8 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
     if (rc != LPG_OK) return rc;
     return check_launch("csr_spmm (rows)");
   }
+  phase_mark(0, st);
+  phase_mark(1, st);
   // d <= 16 in a power of two: the edge-parallel kernel (lanes = edges); wider rows: lanes = feature columns
   const bool narrow = (d == 1 || d == 2 || d == 4 || d == 8 || d == 16) && tune().mode == 0 && !options().spmm_no_edge;
   if (e_cap > 0 && narrow) {
@@ -767,15 +787,28 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
     const int rc = wide ? launch_vec<T, WIDE>(a, e_cap, st) : launch_vec<T, 1>(a, e_cap, st);
     if (rc != LPG_OK) return rc;
   }
-  if (n_empty_hint == 0) return check_launch("csr_spmm");
+  phase_mark(2, st);
+  if (n_empty_hint == 0) {
+    phase_mark(3, st);
+    return check_launch("csr_spmm");
+  }
   const bool wide_out = d % WIDE == 0 && ldy % WIDE == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
   if (wide_out)
     hipLaunchKernelGGL((spmm_empty_rows_kernel<T, WIDE>), dim3(grid_for(N * (d < 64 ? d : 64) / WIDE)), dim3(kBlock), 0, st, a);
   else
     hipLaunchKernelGGL((spmm_empty_rows_kernel<T, 1>), dim3(grid_for(N * (d < 64 ? d : 64))), dim3(kBlock), 0, st, a);
+  phase_mark(3, st);
   return check_launch("csr_spmm");
 }
 }  // namespace
+
+LPG_EXPORT int lpg_csr_spmm_phase_ms(float* out_ms) {
+  LPG_REQUIRE(out_ms, "csr_spmm_phase_ms: null pointer");
+  LPG_REQUIRE(g_phase_recorded, "csr_spmm_phase_ms: no call was timed (set option spmm_phase_timing = 1 first)");
+  LPG_HIP(hipEventSynchronize(g_phase_ev[3]));
+  for (int i = 0; i < 3; ++i) LPG_HIP(hipEventElapsedTime(out_ms + i, g_phase_ev[i], g_phase_ev[i + 1]));
+  return LPG_OK;
+}
 
 LPG_EXPORT int lpg_spmm_chunk_edges(int64_t e_cap) { return chunk_for(e_cap); }
 

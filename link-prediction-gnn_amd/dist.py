@@ -232,6 +232,18 @@ class SourcePartitionedSpMM:
         return full[: self.n_nodes]
 
 
+    def preallocate(self, x_local):
+        """every buffer a forward of either exchange form allocates, up front: a rank that cannot get them fails HERE,
+        before any peer has entered a collective (bench.py agrees on the outcome before the first exchange)."""
+        d, dt, dev = x_local.shape[1], x_local.dtype, x_local.device
+        self._buffers(d, dt, dev)
+        held = [torch.empty((self.shard, d), dtype=dt, device=dev)]
+        if hasattr(self, "out_splits"):
+            for s in range(min(self.n_stages, 3)):
+                held.append(torch.empty((sum(self.out_splits[s]), d), dtype=dt, device=dev))
+                held.append(torch.empty((int(self.send_idx[s].numel()), d), dtype=dt, device=dev))
+        del held                                          # back to torch's caching allocator: the forwards reuse them
+
     def compute_only(self, x_local):
         """the stage SpMMs of one step without any exchange (bench.py reports it next to the whole step)."""
         bufs = self._buffers(x_local.shape[1], x_local.dtype, x_local.device)
@@ -334,10 +346,11 @@ class ShardedLinkScorer:
     ``lpgnn_amd.seal.extract_subgraphs / gnn_inputs / graph_conv_stack / head``.
     """
 
-    def __init__(self, score_fn: Callable, group=None, world=None, rank=None):
+    def __init__(self, score_fn: Callable, group=None, world=None, rank=None, always_collective=False):
         import torch.distributed as dist
         ready = dist.is_available() and dist.is_initialized()
         self.score_fn, self.group = score_fn, group
+        self.always_collective = bool(always_collective) and ready    # world-size-1 rehearsal of the gather (tests)
         self.world = world if world is not None else (dist.get_world_size(group) if ready else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if ready else 0)
 
@@ -351,7 +364,7 @@ class ShardedLinkScorer:
         mine = self.score_fn(pairs[lo:hi])
         if mine.shape[0] != hi - lo:
             raise ValueError("ShardedLinkScorer: score_fn must return one score per pair")
-        if not gather or self.world == 1:
+        if not gather or (self.world == 1 and not self.always_collective):
             return mine
         width = -(-B // self.world)                       # slices differ by at most one pair: pad to the widest
         send = mine.new_zeros((width,) + tuple(mine.shape[1:]))

@@ -1,0 +1,115 @@
+"""GPU: the RCCL (backend "nccl") branches of lpgnn_amd/dist.py -- reduce_scatter_tensor, all_reduce,
+all_to_all_single with variable splits (async work + the staging ring), all_gather_into_tensor -- which the gloo tests
+cannot reach (gloo takes the emulation branches).  On the one-GPU box: a process group of world size 1 over RCCL in a
+child process, the HIP kernels for everything else, against the unpartitioned SpMM.  With two or more visible GPUs the
+same worker also runs as two real ranks over xGMI.  Also: `python bench.py --gpus 2` starts its own ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rccl_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import lpgnn_amd
+    from lpgnn_amd import dist as ldist
+    gen = torch.Generator().manual_seed(11)              # identical on every rank
+    n, e, d = 40_003, 150_000, 64
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei[1, : e // 2] = torch.randint(0, n // 40, (e // 2,), generator=gen)      # many destination rows receive nothing
+    x = torch.randn((n, d), generator=gen)
+    lo, hi = ldist.source_range(n, world, rank)
+    mine = ldist.partition_edges_by_source(ei, n, world, rank).to(dev)
+    full = lpgnn_amd.CSRGraph.from_edge_index(ei.to(dev), n, n).spmm(x.to(dev))
+    out = {"backend": dist.get_backend()}
+    for collective in ("reduce_scatter", "all_reduce", "sparse"):
+        op = ldist.SourcePartitionedSpMM(mine, n, (lo, hi), n_blocks=5, collective=collective)   # 5 stages > the 3-deep ring
+        for rep in range(2):                              # twice: the staging ring and its pending work are reused
+            y = op.forward(x[lo:hi].to(dev))
+        if collective == "all_reduce":
+            ref = full
+        else:
+            r0 = rank * op.shard
+            ref = torch.zeros((op.shard, d), device=dev)
+            ref[: max(0, min(n, r0 + op.shard) - r0)] = full[r0:r0 + op.shard]
+        out[collective] = (float((y - ref).abs().max()), float(ref.abs().max()), op.collective,
+                           bool(op.graphs_packed), tuple(y.shape))
+
+    def score_fn(p):                                      # stands in for the single-GPU SEAL scorer
+        return (p[:, 0] * 1000 + p[:, 1]).to(torch.float32)
+
+    pairs = torch.arange(2 * 1001, dtype=torch.int64, device=dev).view(1001, 2)
+    sc = ldist.ShardedLinkScorer(score_fn, always_collective=True)             # the all_gather_into_tensor branch
+    out["scores"] = bool(torch.equal(sc(pairs, gather=True), score_fn(pairs)))
+    torch.cuda.synchronize()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in range(world):
+        out = res[rank]
+        assert out["backend"] == "nccl" and out["scores"]
+        for collective in ("reduce_scatter", "all_reduce", "sparse"):
+            err, scale, used, packed, _ = out[collective]
+            assert used == collective and packed == (collective == "sparse")
+            assert err <= 1e-5 * (scale + 1.0), (rank, collective, err)
+
+
+def test_rccl_collectives_world1():
+    """world size 1 over RCCL: every collective call of dist.py executes on the GPU box (dist.py: reduce_scatter_tensor,
+    all_reduce, all_to_all_single, all_gather_into_tensor) and reproduces the unpartitioned SpMM."""
+    _run(1)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
+def test_rccl_collectives_world2():
+    """two real ranks over xGMI: source-edge partition + each exchange form against the single-GPU SpMM."""
+    _run(2)
+
+
+def test_bench_launches_its_own_ranks():
+    """plain `python bench.py --gpus 2` (no launcher around it) starts two ranks as child processes and prints ONE
+    JSON line; rehearsed over gloo with both ranks on this box's one GPU (LPG_BENCH_BACKEND=gloo), small graph."""
+    env = dict(os.environ, LPG_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--nodes", "200000", "--edges", "2000000", "--no-twowl", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["collective"] in ("sparse", "reduce_scatter")

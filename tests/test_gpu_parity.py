@@ -1371,6 +1371,8 @@ def test_linear_bf16_mfma(dev, n, k, m, km):
     ("f32", 20011, 100, 20, 100, False, "relu", True),      # k padded 100 -> 128 in LDS, m < one column tile
     ("f32", 20011, 30, 7, 32, True, None, True),            # ragged k inside a 16-byte piece, padded rows
     ("f32", 17000, 128, 200, 128, False, None, True),       # two column blocks
+    ("f32", 50011, 128, 128, 128, False, "relu", True),     # above the automatic threshold of 128-wide fp32 outputs (49152 rows)
+    ("f32", 49500, 128, 200, 128, False, None, True),       # ... with two column blocks
     ("bf16", 20011, 128, 128, 128, False, None, True),
     ("bf16", 20011, 256, 128, 256, False, "relu", False),
     ("bf16", 20011, 134, 32, 136, True, "tanh", False),     # SEAL's first layer: [onehot(6) || 128], padded rows
@@ -1378,12 +1380,16 @@ def test_linear_bf16_mfma(dev, n, k, m, km):
     ("bf16", 20011, 100, 20, 104, False, "relu", True),
 ])
 def test_linear_persistent_w_resident(dev, lpg_options, variant, dtype, n, k, m, ldx, km, act, bias):
-    """n >= 16384 takes the persistent W-resident kernels (csrc/linear_wres.hip); both variants and the
-    shape-based choice against an fp64 matmul of the same (rounded) inputs; NaN in the row padding must
-    never reach the result."""
-    from lpgnn_amd import ops
+    """the persistent W-resident kernels (csrc/linear_wres.hip), taken automatically from 16384 rows (49152 for fp32
+    outputs wider than 64): every variant forced (forced variants also run below the threshold) and the shape-based
+    choice, against an fp64 matmul of the same (rounded) inputs; NaN in the row padding must never reach the
+    result.  The library's launch statistic proves which path ran."""
+    from lpgnn_amd import _lib, ops
     if variant != "auto":
         lpg_options(linear_wres=int(variant))              # forced variants also run below the automatic row threshold
+    lpg_options(stat_linear_wres=0)
+    n_min = 49152 if (dtype == "f32" and m > 64) else 16384
+    expect_wres = variant != "auto" or n >= n_min
     rng = np.random.default_rng(n + k + m)
     dt = torch.float32 if dtype == "f32" else torch.bfloat16
     xb = torch.from_numpy(rng.standard_normal((n, ldx)).astype(np.float32)).to(dev).to(dt)
@@ -1399,6 +1405,7 @@ def test_linear_persistent_w_resident(dev, lpg_options, variant, dtype, n, k, m,
     mag = np.abs(x64) @ np.abs(w64) + (np.abs(b) if bias else 0.0)
     got = ops.linear(xt, wt, None if b is None else torch.from_numpy(b).to(dev), w_is_km=km, act=act)
     assert got.shape == (n, m) and got.dtype == dt
+    assert (_lib.get_option("stat_linear_wres") >= 1) == expect_wres, "not the kernel this row is meant to test"
     got = _np(got.float()).astype(np.float64)
     if act == "relu":
         want = np.maximum(want, 0)
