@@ -64,7 +64,10 @@ class TrainGraph:
 
 
 def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
-    positive = torch.as_tensor(np.asarray(positive), dtype=torch.int64, device=device)
+    """positive: [P, 2] node pairs (numpy array or tensor, host or device); the last test_ratio of them are held out."""
+    if not torch.is_tensor(positive):
+        positive = torch.from_numpy(np.ascontiguousarray(np.asarray(positive), dtype=np.int64))
+    positive = positive.to(device=device, dtype=torch.int64)
     test_size = int(len(positive) * test_ratio)
     train_pos = positive[: len(positive) - test_size] if test_size > 0 else positive
     if positive.is_cuda and n_nodes <= 8192:

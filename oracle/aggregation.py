@@ -211,3 +211,120 @@ def seal_head(z, key, hw):
     pre_y = dense @ np.asarray(hw["weight_2"], dtype=np.float64) + np.asarray(hw["bias_2"], dtype=np.float64)
     e = np.exp(pre_y - pre_y.max())
     return pre_y, float(e[1] / e.sum())
+
+
+# ----------------------------------------------------------------------------- stage-by-stage forward + error bound
+def graph_norm_bound(x, err, weight, mean_scale, eps=1e-5):
+    """first-order bound on |GraphNorm(x + dx) - GraphNorm(x)| for |dx| <= err (elementwise):
+    y = w o / s + b with o = x - ms * mean(x), s = sqrt(mean(o^2) + eps), so
+    |d mean| <= mean(err) =: em, |d o| <= err + |ms| em =: eo, |d s| <= mean(|o| eo) / s,
+    |d y| <= |w| / s * eo + |w| |o| / s^2 * |d s|."""
+    x = np.asarray(x, dtype=np.float64)
+    w, ms = np.abs(np.asarray(weight, dtype=np.float64))[None, :], np.asarray(mean_scale, dtype=np.float64)[None, :]
+    o = x - x.mean(axis=0, keepdims=True) * ms
+    s = np.sqrt((o * o).mean(axis=0, keepdims=True) + eps)
+    eo = err + np.abs(ms) * err.mean(axis=0, keepdims=True)
+    es = (np.abs(o) * eo).mean(axis=0, keepdims=True) / s
+    return w / s * eo + w * np.abs(o) / (s * s) * es
+
+
+def graph_norm_mag(x, weight, bias, mean_scale, eps=1e-5):
+    """the magnitude GraphNorm's own arithmetic works on: |w| (|x| + |ms mean|) / s + |b|"""
+    x = np.asarray(x, dtype=np.float64)
+    w, ms = np.abs(np.asarray(weight, dtype=np.float64))[None, :], np.asarray(mean_scale, dtype=np.float64)[None, :]
+    mean = x.mean(axis=0, keepdims=True)
+    o = x - mean * ms
+    s = np.sqrt((o * o).mean(axis=0, keepdims=True) + eps)
+    return w * (np.abs(x) + np.abs(mean * ms)) / s + np.abs(np.asarray(bias, dtype=np.float64))[None, :]
+
+
+def localwl_forward_stages(params, x_deg, edge1, pos, idx, ei2, tol=1e-5):
+    """LocalWLNet.forward (TwoWL/model/model.py:68-84) one stage at a time, fp64, with a running first-order error
+    bound for an implementation whose every stage is accurate to tol * (the magnitude that stage sums).
+
+    Returns a list of stage records {name, kind, inputs..., out, mag, bound}:
+      out   -- the stage's fp64 output,
+      mag   -- the magnitude of the stage's own arithmetic (what `tol` is relative to when the stage is fed exact input),
+      bound -- elementwise bound on the accumulated error of `out` when every stage so far errs by tol * its mag:
+               bound_out = (stage's first-order sensitivity applied to bound_in) + tol * mag.
+    The per-stage parity tests use (inputs, out, mag); the whole-forward test uses the last record's bound."""
+    from .twowl_int import reverse
+    edge2, edge2_r = reverse(ei2)
+    p = params
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    stages = []
+
+    def gn_stage(name, x, err, prefix, relu):
+        w, b, ms = p[f"{prefix}.weight"], p[f"{prefix}.bias"], p[f"{prefix}.mean_scale"]
+        out = graph_norm(x, w, b, ms)
+        mag = graph_norm_mag(x, w, b, ms)
+        bound = graph_norm_bound(x, err, w, ms) + tol * mag
+        if relu:
+            out = np.maximum(out, 0.0)                       # 1-Lipschitz: the bound carries over
+        stages.append({"name": name, "kind": "graph_norm", "x": x, "norm": prefix, "relu": relu, "out": out, "mag": mag,
+                       "bound": bound})
+        return out, bound
+
+    def conv_stage(name, x, err, prefix, edge):
+        wt, b = f64(p[f"{prefix}.lin.weight"]).T, f64(p[f"{prefix}.bias"])
+        n = x.shape[0]
+        ei, w = gcn_norm(edge, n)
+        h, mag_h = x @ wt, np.abs(x) @ np.abs(wt)
+        err_h = err @ np.abs(wt) + tol * mag_h
+
+        def aggregate(v):
+            o = np.zeros((n, v.shape[1]))
+            np.add.at(o, ei[1], v[ei[0]] * w[:, None])      # w >= 0
+            return o
+        out = aggregate(h) + b[None, :]
+        mag = aggregate(mag_h) + np.abs(b)[None, :]
+        bound = aggregate(err_h) + tol * (aggregate(np.abs(h)) + np.abs(b)[None, :])
+        stages.append({"name": name, "kind": "gcn_conv", "x": x, "conv": prefix, "edge": edge, "out": out, "mag": mag,
+                       "bound": bound})
+        return out, bound
+
+    x0 = f64(p["emb.weight"])[np.asarray(x_deg, dtype=np.int64)]
+    x, err = gn_stage("emb+norm", x0, np.zeros_like(x0), "emb_norm", False)
+    stages[-1]["kind"], stages[-1]["x_deg"] = "embedding_graph_norm", np.asarray(x_deg, dtype=np.int64)
+    for l in range(p["depth1"]):
+        y, ey = conv_stage(f"conv1s.{l}.conv", x, err, f"conv1s.{l}", edge1)
+        x, err = gn_stage(f"conv1s.{l}.norm", y, ey, f"conv1s.{l}.norm", bool(p[f"conv1s.{l}.act"]))
+    pos = np.asarray(pos, dtype=np.int64)
+    a, b_ = x[pos[:, 0]], x[pos[:, 1]]
+    ea, eb = err[pos[:, 0]], err[pos[:, 1]]
+    h = a * b_
+    err = np.abs(a) * eb + np.abs(b_) * ea + ea * eb + tol * np.abs(h)
+    stages.append({"name": "pair", "kind": "pair", "x": x, "pos": pos, "out": h, "mag": np.abs(h), "bound": err})
+    x = h
+    for l in range(p["depth2"]):
+        outs, ys = [], []
+        for name, e in (("conv2s", edge2), ("conv2s_r", edge2_r)):
+            y, ey = conv_stage(f"{name}.{l}.conv", x, err, f"{name}.{l}", e)
+            ys.append(y)
+            outs.append(gn_stage(f"{name}.{l}.norm", y, ey, f"{name}.{l}.norm", True))
+        x = outs[0][0] + outs[1][0]
+        err = outs[0][1] + outs[1][1] + tol * (np.abs(outs[0][0]) + np.abs(outs[1][0]))
+        # "a" + GraphNorm_r(y_r): an implementation may fuse the sum into the second normalisation (y_r, norm_r given)
+        stages.append({"name": f"sum.{l}", "kind": "sum", "a": outs[0][0], "b": outs[1][0], "y_r": ys[1],
+                       "norm_r": f"conv2s_r.{l}.norm", "out": x,
+                       "mag": np.abs(outs[0][0]) + stages[-1]["mag"], "bound": err})
+    idx = np.asarray(idx, dtype=np.int64)
+    xx, ee = x[idx], err[idx]
+    z = xx[0::2] * xx[1::2]
+    ez = np.abs(xx[0::2]) * ee[1::2] + np.abs(xx[1::2]) * ee[0::2] + ee[0::2] * ee[1::2] + tol * np.abs(z)
+    wt, b = f64(p["pred.weight"]).T, f64(p["pred.bias"])
+    out = z @ wt + b[None, :]
+    mag = np.abs(z) @ np.abs(wt) + np.abs(b)[None, :]
+    stages.append({"name": "readout", "kind": "readout", "x": x, "idx": idx, "out": out, "mag": mag,
+                   "bound": ez @ np.abs(wt) + tol * mag})
+    return stages
+
+
+def seal_head_mag(z, key, hw):
+    """the magnitude chain of seal_head: the same four linear levels on |inputs| and |weights| (ReLU of a
+    non-negative value is the identity), i.e. sum |w x| at the pre-softmax logits.  A head whose every level is
+    accurate to tol * (its magnitude) is within 4 * tol * seal_head_mag of the fp64 logits: the level's own error
+    plus the previous levels' errors carried through |weights| are each <= tol * (this chain)."""
+    az = {k: np.abs(np.asarray(v, dtype=np.float64)) for k, v in hw.items()}
+    pre_y, _ = seal_head(np.abs(np.asarray(z, dtype=np.float64)), key, az)
+    return pre_y

@@ -37,6 +37,29 @@ def rand_graph(rng, n_rows, n_cols, E, hub=None, empty_frac=0.0):
     return np.stack([src, dst]).astype(np.int64)
 
 
+def seal_conv_oracle(a_tilde, d_inv, x, weights, u=0.0, tol=TOL):
+    """SEAL/model/gnn.py:46-63 in fp64 (== oracle.aggregation.seal_graph_conv) together with an elementwise error bound
+    for an implementation that computes every product and aggregation to `tol` of the magnitude it sums, evaluates
+    tanh to 1e-6 absolute (|tanh| <= 1), and STORES H = Z W and Z with relative rounding `u` (0: fp32 storage;
+    2^-8: bf16 storage, round to nearest even).  D^-1 A~ is non-negative with unit row sums and tanh is 1-Lipschitz,
+    so an error passes through a layer as  E' = D^-1 A~ (E |W|)  plus that layer's own terms.
+    Returns (concat(Z1..Z3), Z4[:, 0], bound on the concat, bound on the key)."""
+    a, d = np.asarray(a_tilde, dtype=np.float64), np.asarray(d_inv, dtype=np.float64)[:, None]
+    z, e = np.asarray(x, dtype=np.float64), np.zeros(np.asarray(x).shape)
+    zs, es = [], []
+    for w in weights:
+        w = np.asarray(w, dtype=np.float64)
+        h = z @ w
+        eh = e @ np.abs(w) + tol * (np.abs(z) @ np.abs(w))
+        eh = eh + u * (np.abs(h) + eh)                      # H rounded when it is stored
+        z = np.tanh(d * (a @ h))
+        e = d * (a @ eh) + tol * (d * (a @ np.abs(h))) + 1e-6
+        e = e + u * (np.abs(z) + e)                         # Z rounded when it is stored
+        zs.append(z)
+        es.append(e)
+    return np.concatenate(zs[:3], axis=1), zs[3][:, 0], np.concatenate(es[:3], axis=1), es[3][:, 0]
+
+
 # ------------------------------------------------------------------ scatter_add / degree (a1)
 def test_degree_bit_exact(dev):
     from lpgnn_amd.twowl import degree
@@ -172,7 +195,7 @@ def test_scatter_add_big_float_lists_group_by_destination(dev, monkeypatch, E):
     monkeypatch.setattr(ops, "SCATTER_SORT_MIN", 1 << 40)
     ref = scatter_add(st, it, dim=0, dim_size=n)
     monkeypatch.setattr(ops, "SCATTER_SORT_MIN", 1 << 16)
-    assert np.all(np.abs(_np(ref) - _np(got)) <= 2 * TOL * scale + 1e-30)
+    assert np.all(np.abs(_np(ref) - _np(got)) <= 2 * TOL * scale + 1e-30)     # two fp32 routes, each within TOL * sum|x| of the exact sum
     # in-place edit of the index: regrouped, not served from the memo
     it[:1000] = 5
     idx2 = idx.copy()
@@ -495,17 +518,13 @@ def test_get_ei2_edge_cases(dev):
 
 
 # ------------------------------------------------------------------ LocalWLNet scoring forward (a5-a8)
-@pytest.mark.parametrize("c1,c2,d1,d2", [(256, 32, 1, 1), (24, 16, 2, 2), (64, 24, 3, 1)])
-def test_localwl_forward_fb_pages_food(dev, tw, c1, c2, d1, d2):
-    """test-split scoring forward of TwoWL/model/train.py:54-60 on the seeded fb-pages-food split:
-    logits within 1e-5 (relative to the logit scale) of the fp64 restatement => identical AUC."""
+def _localwl_case(tw, c1, c2, d1, d2, dev, seed=0):
     from lpgnn_amd import twowl
-    from oracle import aggregation as agg, twowl_int
-    torch.manual_seed(0)
+    from oracle import twowl_int
+    torch.manual_seed(seed)
     ei, pred, ei2 = tw["test_ei"].astype(np.int64), tw["test_pred"].astype(np.int64), tw["test_ei2"].astype(np.int64)
     x_deg = twowl_int.degree(tw["val_ei"].astype(np.int64), 620)       # datasets.py:107-114: split 2 uses edge_indexs[1]
     pos1 = np.concatenate([ei.T, pred.T], axis=0)
-    y_len = pred.shape[1]
     mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=c1, channels_2wl=c2, depth1=d1, depth2=d2)
     with torch.no_grad():               # non-trivial norm parameters
         for name, p in mod.named_parameters():
@@ -513,43 +532,108 @@ def test_localwl_forward_fb_pages_food(dev, tw, c1, c2, d1, d2):
                 p.uniform_(0.6, 1.4)
             elif name.endswith("bias"):
                 p.uniform_(-0.3, 0.3)
-    mod = mod.to(dev).eval()
+    return mod.to(dev).eval(), x_deg, ei, pred, ei2, pos1
+
+
+def _seq_of(mod, prefix):
+    """'conv2s_r.1' / 'conv1s.0.norm' -> the Seq holding that GCNConv / GraphNorm"""
+    name, l = prefix.split(".")[:2]
+    return getattr(mod, name)[int(l)]
+
+
+def _gpu_stage(mod, st, dev):
+    """one stage of LocalWLNet.forward on the HIP kernels, fed the ORACLE's fp64 input rounded to fp32"""
+    from lpgnn_amd import ops
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)
+    kind = st["kind"]
+    with torch.no_grad():
+        if kind == "embedding_graph_norm":
+            nm = mod.emb[1]
+            two = nm(ops.embedding(mod.emb[0].weight, i64(st["x_deg"])))
+            one = ops.embedding_graph_norm(mod.emb[0].weight, i64(st["x_deg"]), nm.weight, nm.bias, nm.mean_scale, nm.eps)
+            assert torch.equal(one, two)
+            return one
+        if kind == "gcn_conv":
+            return _seq_of(mod, st["conv"]).modlist[0](f32(st["x"]), i64(st["edge"]))
+        if kind == "graph_norm":
+            nm = mod.emb[1] if st["norm"] == "emb_norm" else _seq_of(mod, st["norm"]).modlist[1]
+            return nm(f32(st["x"]), relu=st["relu"])
+        if kind == "pair":
+            return ops.pair_gather_mul(f32(st["x"]), i64(st["pos"]))
+        if kind == "sum":              # as the product does it: orientation a added inside orientation r's GraphNorm + ReLU
+            return _seq_of(mod, st["norm_r"]).modlist[1](f32(st["y_r"]), relu=True, add_to=f32(st["a"]))
+        if kind == "readout":
+            return ops.pair_readout(f32(st["x"]), i64(st["idx"]), mod.pred.weight, mod.pred.bias)
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("c1,c2,d1,d2", [(256, 32, 1, 1), (24, 16, 2, 2), (64, 24, 3, 1)])
+def test_localwl_forward_fb_pages_food(dev, tw, c1, c2, d1, d2):
+    """test-split scoring forward of TwoWL/model/train.py:54-60 on the seeded fb-pages-food split.
+
+    Layer by layer (TwoWL/model/model.py:71-83): every stage -- Embedding + GraphNorm, each GCNConv, each GraphNorm
+    (+ ReLU), the pair product, the orientation sum, the readout -- is run on the HIP kernels with the ORACLE's fp64
+    input rounded to fp32 and held to TOL = 1e-5 times the magnitude that stage sums (north star: 1e-5 relative).
+
+    Whole forward: the logits are held to the first-order propagation of those per-stage errors through the network
+    (oracle.aggregation.localwl_forward_stages: |W| for linears, the normalised adjacency for aggregations, and for
+    GraphNorm the sensitivities 1/s and |o|/s^2 of y = w o / s + b -- GraphNorm divides by the column's standard
+    deviation, which is what makes the end-to-end error larger than 1e-5 of the logit scale: an aggregation output
+    whose spread s is small against the magnitudes it summed is amplified by |x| / s).  No free constant: the bound
+    is what a forward accurate to 1e-5 per stage can produce, and the measured error must stay below it."""
+    from lpgnn_amd import twowl
+    from oracle import aggregation as agg
+    mod, x_deg, ei, pred, ei2, pos1 = _localwl_case(tw, c1, c2, d1, d2, dev)
+    y_len = pred.shape[1]
     t = lambda a: torch.from_numpy(a).to(dev)
-    logits = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2))
-    assert logits.shape == (y_len // 2, 1)
     idx = ei.shape[1] + np.arange(y_len)
-    want = agg.localwl_forward(mod.export_params(), x_deg, ei, pos1, idx, ei2)
-    got = _np(logits).astype(np.float64)
+    stages = agg.localwl_forward_stages(mod.export_params(), x_deg, ei, pos1, idx, ei2, tol=TOL)
+    assert np.array_equal(stages[-1]["out"], agg.localwl_forward(mod.export_params(), x_deg, ei, pos1, idx, ei2))
+    assert len(stages) == 1 + 2 * d1 + 1 + 5 * d2 + 1
+    for st in stages:                                   # (1) every stage at 1e-5 of what it sums
+        got = _np(_gpu_stage(mod, st, dev)).astype(np.float64)
+        err = np.abs(got - st["out"])
+        assert np.all(err <= TOL * st["mag"] + 1e-30), (st["name"], float((err / (st["mag"] + 1e-30)).max()))
+    for small in (True, False):                         # (2) the whole forward, both device paths
+        with pytest.MonkeyPatch.context() as mp:
+            mp.setattr(twowl, "_SMALL_PATH", small)
+            assert mod._small_graph_ok(t(x_deg), t(ei), pos1.shape[0]) == small
+            logits = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2))
+            again = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2))
+        assert logits.shape == (y_len // 2, 1) and torch.equal(logits, again)      # atomic-free: bitwise reproducible
+        want, bound = stages[-1]["out"], stages[-1]["bound"]
+        got = _np(logits).astype(np.float64)
+        assert np.all(np.abs(got - want) <= bound), float((np.abs(got - want) / bound).max())
+        y = np.concatenate([np.ones(y_len // 4), np.zeros(y_len // 4)])
+        assert abs(agg.auc(y, got) - agg.auc(y, want)) <= 0.002
     scale = np.abs(want).max() + 1.0
-    assert np.max(np.abs(got - want)) <= 20 * TOL * scale, np.max(np.abs(got - want))
-    y = np.concatenate([np.ones(y_len // 4), np.zeros(y_len // 4)])
-    assert abs(agg.auc(y, got) - agg.auc(y, want)) <= 0.002
-    # same forward again: bitwise identical (atomic-free path)
-    assert torch.equal(logits, twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2)))
+    print(f"LocalWLNet {c1}/{c2}/{d1}/{d2}: max |logit error| {np.abs(got - want).max():.2e}, propagated bound "
+          f"{bound.max():.2e} = {bound.max() / (TOL * scale):.1f} x (1e-5 x logit scale)")
 
 
 # ------------------------------------------------------------------ small-graph GCN blocks (the launch-bound regime)
 def test_localwl_small_path_matches_generic_path(dev, tw, monkeypatch):
-    """the two-launches-per-block path (default for <= 8192 rows) and the kernel-per-op path agree to fp32
-    rounding on the fb-pages-food forward; each is held to the oracle by test_localwl_forward_fb_pages_food."""
+    """the two-launches-per-block path (default for <= 8192 rows) and the kernel-per-op path on the fb-pages-food
+    forward: each within the propagated 1e-5-per-stage bound of the fp64 oracle (see
+    test_localwl_forward_fb_pages_food), hence within twice that bound of each other."""
     from lpgnn_amd import twowl
-    from oracle import twowl_int
-    torch.manual_seed(3)
+    from oracle import aggregation as agg
     t = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
-    ei, pred, ei2 = t(tw["test_ei"]), t(tw["test_pred"]), t(tw["test_ei2"])
-    x_deg = t(twowl_int.degree(tw["val_ei"].astype(np.int64), 620))
-    pos1 = torch.cat([ei.t(), pred.t()], 0).contiguous()
-    monkeypatch.setattr(twowl, "_SMALL_PATH", True)            # whatever LPG_TWOWL_SMALL says in the environment
     for c1, c2, d1, d2 in [(256, 32, 1, 1), (32, 24, 2, 2)]:
-        mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=c1, channels_2wl=c2, depth1=d1, depth2=d2).to(dev).eval()
-        assert mod._small_graph_ok(x_deg, ei, pos1.shape[0])
-        small = twowl.test_forward(mod, x_deg, ei, pos1, pred.shape[1], ei2)
-        monkeypatch.setattr(twowl, "_SMALL_PATH", False)
-        assert not mod._small_graph_ok(x_deg, ei, pos1.shape[0])
-        generic = twowl.test_forward(mod, x_deg, ei, pos1, pred.shape[1], ei2)
+        mod, x_deg, ei, pred, ei2, pos1 = _localwl_case(tw, c1, c2, d1, d2, dev, seed=3)
+        idx = ei.shape[1] + np.arange(pred.shape[1])
+        last = agg.localwl_forward_stages(mod.export_params(), x_deg, ei, pos1, idx, ei2, tol=TOL)[-1]
         monkeypatch.setattr(twowl, "_SMALL_PATH", True)
-        scale = float(generic.abs().max()) + 1.0
-        assert float((small - generic).abs().max()) <= 20 * TOL * scale
+        assert mod._small_graph_ok(t(x_deg), t(ei), pos1.shape[0])
+        small = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), pred.shape[1], t(ei2))
+        monkeypatch.setattr(twowl, "_SMALL_PATH", False)
+        assert not mod._small_graph_ok(t(x_deg), t(ei), pos1.shape[0])
+        generic = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), pred.shape[1], t(ei2))
+        monkeypatch.setattr(twowl, "_SMALL_PATH", True)
+        for got in (small, generic):
+            assert np.all(np.abs(_np(got).astype(np.float64) - last["out"]) <= last["bound"])
+        assert np.all(np.abs(_np(small).astype(np.float64) - _np(generic)) <= 2 * last["bound"])
 
 
 @pytest.mark.parametrize("n,k,m", [(620, 256, 32), (4252, 32, 32), (1, 24, 16), (7, 64, 24), (1030, 100, 40),
@@ -639,34 +723,52 @@ def test_small_gcn_deferred_norm(dev, n, E, c, shape, rb, monkeypatch):
     eye = np.eye(c)
     ya = agg.gcn_conv(h.astype(np.float64), ei, eye, b1.astype(np.float64))
     yr = agg.gcn_conv(h2.astype(np.float64), np.ascontiguousarray(ei[::-1]), eye, b2.astype(np.float64))
-    for got, want in ((a, ya), (r, yr)):
-        assert np.abs(_np(got.y) - want).max() <= 20 * TOL * (np.abs(want).max() + 1.0)
-        assert np.allclose(_np(got.part[:, 0].sum(0)), want.sum(0), rtol=1e-5, atol=1e-4)
-        assert np.allclose(_np(got.part[:, 1].sum(0)), (want * want).sum(0), rtol=1e-4, atol=1e-4)
+    # magnitude the aggregation sums: A_hat |h| + |b| (A_hat >= 0)
+    ma = agg.gcn_conv(np.abs(h).astype(np.float64), ei, eye, np.abs(b1).astype(np.float64))
+    mr = agg.gcn_conv(np.abs(h2).astype(np.float64), np.ascontiguousarray(ei[::-1]), eye, np.abs(b2).astype(np.float64))
+    for got, want, mag in ((a, ya, ma), (r, yr, mr)):
+        assert np.all(np.abs(_np(got.y) - want) <= TOL * mag + 1e-30)
+        # column sums of y and y^2 (what the deferred GraphNorm is computed from): d(y^2) = 2 y dy <= 2 TOL mag^2
+        assert np.all(np.abs(_np(got.part[:, 0].sum(0)) - want.sum(0)) <= TOL * mag.sum(0) + 1e-30)
+        assert np.all(np.abs(_np(got.part[:, 1].sum(0)) - (want * want).sum(0)) <= 2 * TOL * (mag * mag).sum(0) + 1e-30)
     xa64, xr64 = nm1.ref(ya, True), nm2.ref(yr, False)
-    tol = lambda want: 50 * TOL * (np.abs(want).max() + 1.0)
-    assert np.abs(_np(a.materialize()) - xa64).max() <= tol(xa64)
+    # GraphNorm applied on load: the aggregation's error (TOL * mag) through GraphNorm's first-order sensitivities, plus
+    # the normalisation's own arithmetic at TOL of what it sums (oracle.aggregation.graph_norm_bound / _mag)
+    gnb = lambda y, mag, nm: (agg.graph_norm_bound(y, TOL * mag, _np(nm.weight), _np(nm.mean_scale), nm.eps)
+                              + TOL * agg.graph_norm_mag(y, _np(nm.weight), _np(nm.bias), _np(nm.mean_scale), nm.eps))
+    ba, br = gnb(ya, ma, nm1), gnb(yr, mr, nm2)
+    assert np.all(np.abs(_np(a.materialize()) - xa64) <= ba)
+    # a consumer linear over N(.): input error through |W|, plus TOL of what the product sums
+    lin_tol = lambda x64, bx, ww: ((bx @ np.abs(ww.astype(np.float64)).T) + TOL * (np.abs(x64) @ np.abs(ww.astype(np.float64)).T)).T
     # consumers: linear (plain / pair / sum), readout
     m = 7
     w, w2 = f(m, c), f(m, c)
     hT = ops.small_linear_t(a, d(w))
     want = (xa64 @ w.astype(np.float64).T).T
-    assert np.abs(_np(hT[:, :n]) - want).max() <= tol(want) * c
+    assert np.all(np.abs(_np(hT[:, :n]) - want) <= lin_tol(xa64, ba, w))
     hT, h2T = ops.small_linear_t(a, d(w), d(w2), xb=r)
+    xs64, bs = xa64 + xr64, ba + br + TOL * (np.abs(xa64) + np.abs(xr64))
     for got, ww in ((hT, w), (h2T, w2)):
-        want = ((xa64 + xr64) @ ww.astype(np.float64).T).T
-        assert np.abs(_np(got[:, :n]) - want).max() <= tol(want) * c
+        want = (xs64 @ ww.astype(np.float64).T).T
+        assert np.all(np.abs(_np(got[:, :n]) - want) <= lin_tol(xs64, bs, ww))
     npair = 2 * n + 3
     pos = rng.integers(0, n, size=(npair, 2))
     hT = ops.small_linear_t(a, d(w), pos=d(pos))
-    want = ((xa64[pos[:, 0]] * xa64[pos[:, 1]]) @ w.astype(np.float64).T).T
-    assert np.abs(_np(hT[:, :npair]) - want).max() <= tol(want) * c
+    pa, pb_ = xa64[pos[:, 0]], xa64[pos[:, 1]]
+    ea, eb = ba[pos[:, 0]], ba[pos[:, 1]]
+    xp64, bp = pa * pb_, np.abs(pa) * eb + np.abs(pb_) * ea + ea * eb + TOL * np.abs(pa * pb_)
+    want = (xp64 @ w.astype(np.float64).T).T
+    assert np.all(np.abs(_np(hT[:, :npair]) - want) <= lin_tol(xp64, bp, w))
     idx = rng.integers(0, n, size=2 * 50)
     pw, pb = f(1, c), f(1)
-    for rr, x64 in ((r, xa64 + xr64), (None, xa64)):
+    for rr, x64, bx in ((r, xs64, bs), (None, xa64, ba)):
         got = ops.small_readout(a, rr, d(idx), d(pw), d(pb))
         want = agg.pair_readout(x64, idx, pw.astype(np.float64), pb.astype(np.float64))
-        assert got.shape == (50, 1) and np.abs(_np(got) - want).max() <= tol(want) * c
+        xx, ee = x64[idx], bx[idx]
+        z = xx[0::2] * xx[1::2]
+        ez = np.abs(xx[0::2]) * ee[1::2] + np.abs(xx[1::2]) * ee[0::2] + ee[0::2] * ee[1::2] + TOL * np.abs(z)
+        bnd = ez @ np.abs(pw.astype(np.float64)).T + TOL * (np.abs(z) @ np.abs(pw.astype(np.float64)).T + np.abs(pb))
+        assert got.shape == (50, 1) and np.all(np.abs(_np(got) - want) <= bnd)
 
 
 def test_small_gcn_random_sweep(dev, monkeypatch):
@@ -699,7 +801,7 @@ def test_small_gcn_random_sweep(dev, monkeypatch):
         w = g.val[:nnz].double()
         want = torch.zeros((n, c), dtype=torch.float64, device=dev).index_add_(0, rows, h.double()[cols] * w[:, None]) + bias.double()
         mag = torch.zeros((n, c), dtype=torch.float64, device=dev).index_add_(0, rows, (h.double()[cols] * w[:, None]).abs()) + bias.double().abs()
-        assert torch.all((out.y.double() - want).abs() <= 4 * TOL * mag + 1e-30), (trial, n, E, c, rb)
+        assert torch.all((out.y.double() - want).abs() <= TOL * mag + 1e-30), (trial, n, E, c, rb)
         assert torch.allclose(out.part[:, 0].sum(0), out.y.double().sum(0), rtol=1e-12, atol=1e-9)
         assert torch.allclose(out.part[:, 1].sum(0), (out.y.double() ** 2).sum(0), rtol=1e-12, atol=1e-9)
 
@@ -718,7 +820,8 @@ def test_embedding_graph_norm(dev):
         two = ops.graph_norm(ops.embedding(d(tab), d(idx)), d(gw), d(gb), d(gms))
         assert torch.equal(got, two)                      # same kernel, gather folded in
         want = agg.graph_norm(tab[idx].astype(np.float64), gw.astype(np.float64), gb.astype(np.float64), gms.astype(np.float64))
-        assert np.abs(_np(got) - want).max() <= 20 * TOL * (np.abs(want).max() + 1.0)
+        mag = agg.graph_norm_mag(tab[idx].astype(np.float64), gw, gb, gms)         # |w| (|x| + |ms mean|) / s + |b|
+        assert np.all(np.abs(_np(got) - want) <= TOL * mag)
 
 
 # ------------------------------------------------------------------ SEAL structure path vs the reference's goldens
@@ -828,9 +931,12 @@ def test_seal_graph_conv_with_reference_weights(dev, sl, golden_dir, path):
         adj = _unpack_adj(bits[gi], nn)
         a_t, dinv, xx = seal_int.gnn_inputs(adj, tm[tags[gi, :nn]], T, emb[nodes[gi, :nn]])
         assert np.array_equal(xh[off[gi]:off[gi + 1]], xx.astype(np.float32))           # a12: exact
-        zc, z4 = agg.seal_graph_conv(a_t, dinv, xx, weights)
-        worst = max(worst, np.abs(z[off[gi]:off[gi + 1]] - zc).max(), np.abs(key[off[gi]:off[gi + 1]] - z4).max())
-    assert worst <= 4 * TOL, worst          # |tanh| <= 1: absolute == relative to the output scale; 4 layers deep
+        zc, z4, bz, bk = seal_conv_oracle(a_t, dinv, xx, weights)                        # 1e-5 per product / aggregation,
+        assert np.array_equal(zc, agg.seal_graph_conv(a_t, dinv, xx, weights)[0])        # propagated through the 4 layers
+        ez, ek = np.abs(z[off[gi]:off[gi + 1]] - zc), np.abs(key[off[gi]:off[gi + 1]] - z4)
+        assert np.all(ez <= bz) and np.all(ek <= bk), (gi, float((ez / bz).max()), float((ek / bk).max()))
+        worst = max(worst, ez.max(), ek.max())
+    print(f"SEAL conv stack ({path}): worst |error| {worst:.2e} on tanh outputs (scale 1)")
 
 
 # ------------------------------------------------------------------ full-size property (north-star shape, scaled)
@@ -956,7 +1062,7 @@ def test_full_size_headline_instance_properties(dev):
     gs = lpgnn_amd.CSRGraph.from_edge_index(ei[:, :m].contiguous(), N, N)
     ref = gs.spmm(x)
     scale = gs.spmm(x.abs())
-    assert torch.all((ys - ref).abs() <= 2 * TOL * scale + 1e-30)
+    assert torch.all((ys - ref).abs() <= 2 * TOL * scale + 1e-30)            # two fp32 routes, each within TOL * sum|x| of the exact sum
     ops._scatter_plans.clear()
 
 
@@ -1126,7 +1232,8 @@ def test_seal_dense_conv_stack_tiny_batches(dev, sl, B):
 def test_seal_dense_conv_stack_matches_generic_at_scale(dev):
     """the dense-block MFMA conv stack against the generic CSR path on a hub-rich synthetic batch (236 K-node RMAT
     graph, 20 K candidate pairs, subgraphs of 2..100 vertices incl. capped ones, max_neighbors = 128 as well):
-    every row of [Z1 | Z2 | Z3] and of the sort key within 2e-5."""
+    every row of [Z1 | Z2 | Z3] and of the sort key within 2 TOL = 2e-5 absolute: both are tanh outputs (scale 1) that
+    test_seal_graph_conv_with_reference_weights holds to the propagated 1e-5-per-layer bound of the fp64 oracle."""
     import bench
     from lpgnn_amd import _lib, seal
     N, E = 235_868, 1_285_465
@@ -1179,9 +1286,12 @@ def test_seal_head_with_reference_weights(dev, sl, golden_dir):
     picks = list(range(0, 4202, 29)) + [int(np.argmax(n)), int(np.argmin(n))]
     for gi in picks:                                    # includes n < k (zero padded) and n > k (truncated)
         want_y, want_s = agg.seal_head(zz[off[gi]:off[gi + 1]], kk[off[gi]:off[gi + 1]], hw_np)
-        scale = np.abs(want_y).max() + 1.0
-        assert np.max(np.abs(py[gi] - want_y)) <= 20 * TOL * scale, (gi, py[gi], want_y)
-        assert abs(sc[gi] - want_s) <= 1e-4
+        # four linear levels (conv1d #1, conv1d #2, dense, logits), each accurate to TOL of what it sums: the logits are
+        # within 4 TOL of the magnitude chain (oracle.aggregation.seal_head_mag); softmax over two classes is
+        # sigmoid(y1 - y0), whose slope is at most 1/4
+        by = 4 * TOL * agg.seal_head_mag(zz[off[gi]:off[gi + 1]], kk[off[gi]:off[gi + 1]], hw_np)
+        assert np.all(np.abs(py[gi] - want_y) <= by), (gi, py[gi], want_y, by)
+        assert abs(sc[gi] - want_s) <= by.sum() / 4 + 1e-7
     # ties in the sort key: lower vertex index first (tf.nn.top_k)
     zt = torch.arange(12, dtype=torch.float32, device=dev).view(6, 2)
     kt = torch.tensor([1.0, 3.0, 3.0, 0.5, 3.0, 2.0], device=dev)
@@ -1318,7 +1428,8 @@ def test_trained_model_auc_parity_fb_pages_food(dev, golden_dir):
     """north-star AUC clause as kernel-substitution parity at a MEANINGFUL AUC: train LocalWLNet on
     the seeded fb-pages-food split with a plain-PyTorch fp32 reference of the model (autograd), then
     score the test split with (a) that torch reference and (b) the HIP kernels on the same weights:
-    logits within 1e-4 of the logit scale, AUC within +-0.002 (and well above chance)."""
+    both within the propagated 1e-5-per-stage bound of the fp64 oracle on those weights (hence within twice that of
+    each other), AUC within +-0.002 (and well above chance)."""
     from lpgnn_amd import data, twowl
     from oracle import aggregation as agg
     from tests import torch_reference as tref
@@ -1335,8 +1446,12 @@ def test_trained_model_auc_parity_fb_pages_food(dev, golden_dir):
     got = twowl.test_forward(mod, x, ei, pos1, y.shape[0], ei2)
     labels = _np(y).reshape(-1)[0::2]
     auc_ref, auc_got = agg.auc(labels, _np(ref).reshape(-1)), agg.auc(labels, _np(got).reshape(-1))
-    scale = float(ref.abs().max()) + 1.0
-    assert float((got - ref).abs().max()) <= 1e-4 * scale, float((got - ref).abs().max())
+    npi = lambda a: _np(a).astype(np.int64)
+    last = agg.localwl_forward_stages(mod.export_params(), npi(x), npi(ei), npi(pos1), npi(idx), npi(ei2), tol=TOL)[-1]
+    for name, out in (("HIP kernels", got), ("torch fp32 reference", ref)):
+        err = np.abs(_np(out).astype(np.float64) - last["out"])
+        assert np.all(err <= last["bound"]), (name, float((err / last["bound"]).max()))
+    assert np.all(np.abs(_np(got).astype(np.float64) - _np(ref)) <= 2 * last["bound"])
     assert abs(auc_ref - auc_got) <= 0.002
     assert auc_ref > 0.75, auc_ref            # the recorded reference runs span 0.79-0.89 (unseeded, 1000 epochs)
     print(f"fb-pages-food test AUC: torch reference {auc_ref:.4f}, HIP kernels {auc_got:.4f}")
@@ -1422,9 +1537,11 @@ def test_linear_persistent_w_resident(dev, lpg_options, variant, dtype, n, k, m,
 
 
 def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
-    """configs[2] numerics: the SEAL graph-conv stack with X, weights and activations stored in
-    bf16 (fp32 accumulate everywhere) stays within bf16 rounding of the fp32 stack."""
+    """configs[2] numerics on the reference's own dataset: the SEAL graph-conv stack with X, weights and activations
+    stored in bf16 (fp32 accumulate everywhere), against the fp64 oracle ON THE bf16-ROUNDED INPUTS, within the bound
+    that storing H and Z in bf16 (2^-8 relative per store) implies layer by layer (seal_conv_oracle(u = 2^-8))."""
     from lpgnn_amd import seal
+    from oracle import seal_int
     wz = np.load(os.path.join(golden_dir, "seal_weights.npz"))
     gw = [torch.from_numpy(wz[f"graph_weight_{i}"]).to(dev) for i in (1, 2, 3, 4)]
     pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
@@ -1432,14 +1549,34 @@ def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
     batch, _, T, tag_map, _ = seal.link2subgraph(pos, neg, 620, 0.1, 1, device=dev)
     g, d_inv, x = seal.gnn_inputs(batch, tag_map, T, emb)                      # T + 122 = 128 columns
     assert x.shape[1] == 128
-    w1 = torch.randn(128, 32, device=dev) * 0.1
-    z32, k32 = seal.graph_conv_stack(g, d_inv, x, [w1] + gw[1:])
-    z16, k16 = seal.graph_conv_stack(g, d_inv, x.bfloat16(), [w1.bfloat16()] + [w.bfloat16() for w in gw[1:]])
-    assert z16.dtype == torch.bfloat16
+    w16 = [(torch.randn(128, 32, device=dev) * 0.1).bfloat16()] + [w.bfloat16() for w in gw[1:]]
     # X stored directly in bf16 by the features kernel == the fp32 X rounded once (round to nearest even)
-    g16, _, x16 = seal.gnn_inputs(batch, tag_map, T, emb, dtype=torch.bfloat16)
+    g16, dinv16, x16 = seal.gnn_inputs(batch, tag_map, T, emb, dtype=torch.bfloat16)
     assert x16.dtype == torch.bfloat16 and x16.stride(0) % 8 == 0 and torch.equal(x16, x.bfloat16())
-    assert float((z16.float() - z32).abs().max()) < 0.03 and float((k16.float() - k32).abs().max()) < 0.03
+    for b in (None, batch):                                                    # generic block-CSR path / with the batch given
+        z16, k16 = seal.graph_conv_stack(g16, dinv16, x16, w16, batch=b)
+        assert z16.dtype == torch.bfloat16
+        _check_seal_stack_bf16(batch, tag_map, T, emb.bfloat16(), w16, x16, z16, k16, list(range(0, 4202, 61)))
+
+
+def _check_seal_stack_bf16(batch, tag_map, T, emb16, w16, x16, z16, k16, picks):
+    """sampled subgraphs of a bf16-storage SEAL conv stack against the fp64 oracle on the bf16-rounded inputs"""
+    from oracle import seal_int
+    off, n, nodes, tags, bits = _np(batch.node_off()), _np(batch.n), _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits)
+    tm = _np(tag_map)
+    emb64 = _np(emb16.float()).astype(np.float64)
+    w64 = [_np(w.float()).astype(np.float64) for w in w16]
+    xh, zz, kk = _np(x16.float()), _np(z16.float()).astype(np.float64), _np(k16.float()).astype(np.float64)
+    worst = 0.0
+    for gi in picks:
+        nn = int(n[gi])
+        a_t, dinv, xx = seal_int.gnn_inputs(_unpack_adj(bits[gi], nn), tm[tags[gi, :nn]], T, emb64[nodes[gi, :nn]])
+        assert np.array_equal(xh[off[gi]:off[gi + 1]].astype(np.float64), xx)           # a12 in bf16: exact
+        zc, z4, bz, bk = seal_conv_oracle(a_t, dinv, xx, w64, u=2.0 ** -8)
+        ez, ek = np.abs(zz[off[gi]:off[gi + 1]] - zc), np.abs(kk[off[gi]:off[gi + 1]] - z4)
+        assert np.all(ez <= bz) and np.all(ek <= bk), (gi, float((ez / bz).max()), float((ek / bk).max()))
+        worst = max(worst, float((ez / bz).max()), float((ek / bk).max()))
+    return worst
 
 
 @pytest.mark.parametrize("chunk", [None, "512"])
@@ -1580,3 +1717,180 @@ def test_seal_train_csr_small_matches_sort_route(dev, sl):
         seal.build_train_csr(np.array([[0, 5]]), 5, 0.0, device=dev)
         from lpgnn_amd import ops
         ops.raise_if_flagged(torch.device(dev))
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[2..4] at their stated shapes
+def _check_extraction_vs_oracle(pairs, graph, batch, A, need_uncapped):
+    """every pair of an extracted batch against oracle.seal_int on a scipy CSR adjacency: node set (bit-exact when the
+    reference's 100-node truncation does not fire; a valid outcome of that branch under the device policy when it
+    does), induced adjacency and DRNL tags bit-exact on the node list actually chosen."""
+    from oracle import seal_int
+    n, nodes, tags, bits, capped = _np(batch.n), _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits), _np(batch.capped)
+    n_unc = 0
+    for g, (u, v) in enumerate(np.asarray(pairs)):
+        want_nodes, want_cap = seal_int.enclosing_nodes((u, v), A, 1)
+        assert bool(capped[g]) == want_cap
+        nd = nodes[g, : n[g]]
+        if not want_cap:
+            n_unc += 1
+            assert nd.tolist() == want_nodes
+        else:
+            cand = set(seal_int.neighbours(A, u).tolist()) | set(seal_int.neighbours(A, v).tolist())
+            assert nd[0] == u and nd[1] == v and n[g] <= 100 and set(nd[2:].tolist()) <= cand - {u, v}
+            assert len(set(nd.tolist())) == n[g]
+        adj = seal_int.induced_adjacency(nd, A)
+        assert np.array_equal(_unpack_adj(bits[g], int(n[g])), adj)
+        assert tags[g, : n[g]].tolist() == seal_int.node_labeling(adj)
+    assert n_unc >= need_uncapped, n_unc
+
+
+def test_config2_collab_seal_bf16_d128(dev):
+    """BASELINE configs[2]: "ogbl-collab" SEAL, 1-hop enclosing subgraphs, d = 128, bf16, one GPU -- on the stand-in
+    SURVEY 8d names (RMAT |V| = 235 868, 1 285 465 undirected edges, seed 1; the dataset itself is not available
+    offline).  2 500 candidate pairs (random + hubs + true edges): extraction -> X = [onehot(DRNL) || 128-d] STORED
+    IN bf16 -> four graph convolutions in bf16 storage -> DGCNN head, all on the HIP path; sampled subgraphs against
+    oracle.aggregation.seal_graph_conv / seal_head in fp64 on the bf16-rounded inputs.  Tolerance: storing H and Z
+    in bf16 is a 2^-8 relative rounding per store, carried through the layers by seal_conv_oracle (derivation in its
+    docstring); the head runs in fp32 on the bf16 activations and is held to 4 x 1e-5 of its magnitude chain."""
+    import bench
+    from lpgnn_amd import seal
+    from oracle import aggregation as agg
+    N, E, D, B = 235_868, 1_285_465, 128, 2500
+    ei = bench.rmat_edges(N, E, 1, dev)
+    und = ei.t().cpu().numpy()
+    graph = seal.build_train_csr(und, N, test_ratio=0.0, device=dev)
+    rng = np.random.default_rng(2)
+    pairs = rng.integers(0, N, size=(B, 2))
+    deg = _np(graph.rowptr[1:] - graph.rowptr[:-1])
+    pairs[:30, 0] = np.argsort(deg)[-30:]                       # hubs: the cap fires
+    pairs[30:130] = und[rng.integers(0, E, 100)]                # true edges
+    batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0)
+    tag_map, T = seal.compact_tag_map(batch)
+    assert 3 <= T <= 8
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    emb16 = torch.randn((N, D), generator=gen, device=dev).bfloat16()
+    g, d_inv, x16 = seal.gnn_inputs(batch, tag_map, T, emb16.float(), dtype=torch.bfloat16)
+    assert x16.dtype == torch.bfloat16 and x16.shape == (batch.total(), T + D)
+    w16 = [(torch.randn(a, b, generator=gen, device=dev) * s).bfloat16()
+           for a, b, s in ((T + D, 32, 0.15), (32, 32, 0.4), (32, 32, 0.4), (32, 1, 0.5))]
+    z16, k16 = seal.graph_conv_stack(g, d_inv, x16, w16, batch=batch)
+    assert z16.dtype == torch.bfloat16 and z16.shape == (batch.total(), 96) and k16.shape == (batch.total(),)
+    n = _np(batch.n)
+    picks = list(range(0, B, 41)) + [int(np.argmax(n)), int(np.argmin(n)), 0, 1, 31, 32]
+    worst = _check_seal_stack_bf16(batch, tag_map, T, emb16, w16, x16, z16, k16, picks)
+    # head (fp32 arithmetic on the bf16 activations), random-init weights of the reference's DGCNN shapes (k = 18)
+    hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, generator=gen, device=dev) * 0.1,
+          "conv1d_kernel_2": torch.randn(5, 16, 32, generator=gen, device=dev) * 0.1,
+          "weight_1": torch.randn(14 * 32, 128, generator=gen, device=dev) * 0.1,
+          "bias_1": torch.randn(128, generator=gen, device=dev) * 0.1,
+          "weight_2": torch.randn(128, 2, generator=gen, device=dev), "bias_2": torch.randn(2, generator=gen, device=dev)}
+    hw_np = {k: _np(v) for k, v in hw.items()}
+    zf, kf = z16.float(), k16.float()
+    pre_y, score = seal.head(zf, kf, batch.node_off(), hw)
+    off, zz, kk, py, sc = _np(batch.node_off()), _np(zf), _np(kf), _np(pre_y), _np(score)
+    for gi in picks:
+        want_y, want_s = agg.seal_head(zz[off[gi]:off[gi + 1]], kk[off[gi]:off[gi + 1]], hw_np)
+        by = 4 * TOL * agg.seal_head_mag(zz[off[gi]:off[gi + 1]], kk[off[gi]:off[gi + 1]], hw_np)
+        assert np.all(np.abs(py[gi] - want_y) <= by) and abs(sc[gi] - want_s) <= by.sum() / 4 + 1e-7
+    print(f"configs[2] bf16 stack: worst error / derived bf16 bound = {worst:.3f}")
+
+
+def test_config3_ppa_shaped_graph(dev):
+    """BASELINE configs[3]: "ogbl-ppa" SEAL, edge-partitioned -- on the stand-in SURVEY 8d names (RMAT |V| = 576 289,
+    30 326 273 undirected edges = 60.65 M nnz, seed 3, d = 58 padded to 64), the parts that fit one GPU: (i) enclosing
+    subgraphs + DRNL on sampled pairs incl. hubs against oracle.seal_int (the average degree is ~105, so the
+    reference's 100-node cap fires on most pairs); (ii) ShardedLinkScorer's shards extract exactly what one batch
+    does; (iii) the full-graph d = 64 SpMM through size-independent properties (degree bit-exact, column checksum in
+    fp64, exact x2 linearity, bitwise reproducibility, sampled rows vs fp64 gather-sums)."""
+    import scipy.sparse as sp
+    import bench
+    import lpgnn_amd
+    from lpgnn_amd import dist as ldist, ops, seal
+    N, E, d = 576_289, 30_326_273, 64
+    ei = bench.rmat_edges(N, E, 3, dev)
+    graph = seal.build_train_csr(ei.t().contiguous(), N, test_ratio=0.0, device=dev)
+    rp, cl = _np(graph.rowptr), _np(graph.col[: int(graph.rowptr[-1])])
+    A = sp.csr_matrix((np.ones(cl.size, dtype=np.uint8), cl, rp), shape=(N, N))
+    deg = np.diff(rp)
+    rng = np.random.default_rng(3)
+    low = np.nonzero((deg > 0) & (deg < 30))[0]
+    pairs = rng.integers(0, N, size=(400, 2))
+    pairs[:20, 0] = np.argsort(deg)[-20:]                       # hubs with tens of thousands of neighbours
+    pairs[20:220] = low[rng.integers(0, low.size, size=(200, 2))]   # low-degree pairs: the cap does not fire
+    und = _np(ei[:, :4096].t())
+    pairs[220:260] = und[rng.integers(0, und.shape[0], 40)]     # true edges
+    batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=5)
+    _check_extraction_vs_oracle(pairs, graph, batch, A, need_uncapped=150)
+    for world in (2, 8):                                        # 8e (i): shards == one batch
+        for r in range(world):
+            lo, hi = ldist.source_range(len(pairs), world, r)
+            part = seal.extract_subgraphs(pairs[lo:hi], graph, 1, cap_policy="device", seed=5)
+            assert torch.equal(part.n, batch.n[lo:hi]) and torch.equal(part.nodes, batch.nodes[lo:hi])
+            assert torch.equal(part.tags, batch.tags[lo:hi]) and torch.equal(part.adj_bits, batch.adj_bits[lo:hi])
+    scorer = [ldist.ShardedLinkScorer(lambda p: seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=5).n.float(),
+                                      world=4, rank=r) for r in range(4)]
+    tp = torch.from_numpy(pairs).to(dev)
+    assert torch.equal(torch.cat([s_(tp, gather=False) for s_ in scorer]), batch.n.float())
+    del A, batch
+    # (iii) the message-passing graph: both directions of every undirected edge = 60.65 M nnz
+    both = torch.cat([ei, ei.flip(0)], dim=1)
+    del ei
+    _spmm_properties(dev, both, N, d, torch.float32, seed=303)
+
+
+def _spmm_properties(dev, ei, N, d, dtype, seed, w_dense=None):
+    """size-independent checks of Y = A @ X on a graph too big for the CPU oracle: degree() == bincount (int64,
+    bit-exact), CSR row lengths == in-degrees, column checksum sum_r Y[r, :] == sum_j outdeg(j) X[j, :] in fp64,
+    exact linearity under x2, bitwise run-to-run reproducibility, sampled rows (incl. the heaviest) against fp64
+    gather-sums; with w_dense [d, d]: the composite linear(W) o SpMM on those rows against fp64 as well."""
+    import lpgnn_amd
+    from lpgnn_amd import ops
+    E = ei.shape[1]
+    deg = ops.degree(ei[1], N)
+    assert torch.equal(deg, torch.bincount(ei[1], minlength=N))
+    g = lpgnn_amd.CSRGraph.from_edge_index(ei, N, N)
+    assert g.nnz() == E and torch.equal(g.rowptr[1:] - g.rowptr[:-1], deg)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    x = torch.randn((N, d), generator=gen, device=dev).to(dtype)
+    y = g.spmm(x)
+    assert y.dtype == dtype and torch.equal(g.spmm(x), y)
+    assert torch.equal(g.spmm(x * 2), y * 2)                    # powers of two commute with every rounding
+    u = 2.0 ** -8 if dtype == torch.bfloat16 else 0.0           # one rounding of the fp32 accumulator at the store
+    outdeg = torch.bincount(ei[0], minlength=N).double()
+    want, mag = outdeg @ x.double(), outdeg @ x.double().abs()
+    got = y.double().sum(0)
+    # per element |y - exact| <= u |exact| + TOL mag_row, and sum_r |exact| <= sum_j outdeg_j |x_j| = mag
+    assert torch.all((got - want).abs() <= (u + TOL) * mag)
+    rows = torch.cat([torch.randint(0, N, (40,), generator=gen, device=dev), deg.topk(3).indices])
+    for r in rows.tolist():
+        src = ei[0][ei[1] == r]
+        b, e = int(g.rowptr[r]), int(g.rowptr[r + 1])
+        assert torch.equal(g.col[b:e].long(), src)              # stable: edge order kept
+        ref, mg = x[src].double().sum(0), x[src].double().abs().sum(0)
+        assert torch.all((y[r].double() - ref).abs() <= u * ref.abs() + TOL * mg + 1e-30)
+    if w_dense is not None:                                     # the "dense feature update": (A X) W^T on the matrix cores
+        z = ops.linear(y, w_dense)
+        assert z.dtype == dtype and z.shape == (N, w_dense.shape[0])
+        for r in rows.tolist():
+            yr, wd = y[r].double(), w_dense.double()
+            ref, mg = wd @ yr, wd.abs() @ yr.abs()
+            assert torch.all((z[r].double() - ref).abs() <= u * ref.abs() + TOL * mg + 1e-30)
+    return g, x, y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_config4_rmat_10m_200m_d256(dev, dtype):
+    """BASELINE configs[4]: synthetic RMAT |V| = 10 M, |E| = 200 M, d = 256 CSR-SpMM with the MFMA dense feature update
+    (W [256, 256]) -- the whole problem on ONE GPU (10 GB of X, 10 GB of Y, 3.2 GB of edge list: nothing at 288 GB),
+    fp32 and bf16 storage, through the size-independent properties of _spmm_properties, plus the composite
+    linear(W) o SpMM on sampled rows against fp64 (generator seed 4, duplicates kept)."""
+    import bench
+    N, E, d = 10_000_000, 200_000_000, 256
+    ei = bench.rmat_edges(N, E, 4, dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(44)
+    w = (torch.randn((d, d), generator=gen, device=dev) / 16).to(dtype)
+    _spmm_properties(dev, ei, N, d, dtype, seed=404, w_dense=w)
+    torch.cuda.empty_cache()
