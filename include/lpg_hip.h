@@ -251,6 +251,16 @@ int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C
                           const float* gn_mean_scale_r, int64_t row_blocks_r, int relu_r, float eps,
                           const int64_t* idx, int64_t B, const float* w, const float* b0,
                           float* out, int32_t* err_flag, void* stream);
+/* The whole small-graph scoring forward of LocalWLNet (TwoWL/model/model.py:68-84; the timed call of
+ * TwoWL/model/train.py:54-60) as ONE call: `block` (HOST memory, n_words int64 words) lists the forward's launches in
+ * order as { op, a_0 .. a_{k-1} } -- op 1: lpg_embedding_graphnorm_f32 (k = 12), 2: lpg_small_linear_t_f32 (27),
+ * 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23); a_i = that entry point's i-th argument (pointers and
+ * integers as they are, `float eps` as the bit pattern of a double; the trailing stream argument is left out).  Every
+ * launch goes through the same entry point as the one-by-one path and is enqueued on `stream`: same kernels, same
+ * results, one host call per forward instead of six (the forward is launch-bound: 205 -> ~60 us eager).
+ * The host mirror builds the block once per (model, graph, candidate set): lpgnn_amd.twowl.LocalWLNet. */
+int lpg_twowl_forward_small(const int64_t* block, int64_t n_words, void* stream);
+
 
 /* ---------------------------------------------------------------- 2-WL tuple graph (a3, a2)
  * get_ei2(n_node, pos_edge, pred_edge) [TwoWL/utils.py:36-45]: tuple ids = columns of

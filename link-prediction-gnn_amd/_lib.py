@@ -101,6 +101,54 @@ class options:
         return False
 
 
+# ---- recording of launch sequences (lpg_twowl_forward_small's argument block) --------------------------------------
+_REC_OPS = {"lpg_embedding_graphnorm_f32": (1, 12, (8,)), "lpg_small_linear_t_f32": (2, 27, (25,)),
+            "lpg_small_gcn_f32": (3, 20, ()), "lpg_small_readout_f32": (4, 23, (16,))}
+_rec = None            # while recording: {"words": [...], "keep": [...]}
+
+
+def call(name, *args):
+    """lib.<name>(*args) with the return code checked; while a recording is open the launch is also appended to it as
+    { op, a_0 .. a_{k-1} } words (stream left out, floats as the bits of a double): include/lpg_hip.h,
+    lpg_twowl_forward_small."""
+    rc = check(getattr(load(), name)(*args), name)
+    if _rec is not None:
+        import struct
+        op, k, floats = _REC_OPS[name]
+        if len(args) != k + 1:
+            raise LpgError(f"{name}: recorded with {len(args)} arguments, the block layout has {k} + stream")
+        words = [op]
+        for i, a in enumerate(args[:k]):
+            if i in floats:
+                words.append(struct.unpack("<q", struct.pack("<d", float(a)))[0])
+            else:
+                words.append(0 if a is None else int(a))
+        _rec["words"].extend(words)
+    return rc
+
+
+def keepalive(*tensors):
+    """tensors whose device pointers went into a recorded launch must outlive the recording"""
+    if _rec is not None:
+        _rec["keep"].extend(t for t in tensors if t is not None)
+
+
+class recording:
+    """with _lib.recording() as rec: ...   ->  rec["words"] (the block), rec["keep"] (tensors to hold on to)"""
+
+    def __enter__(self):
+        global _rec
+        if _rec is not None:
+            raise LpgError("a launch recording is already open")
+        _rec = {"words": [], "keep": []}
+        return _rec
+
+    def __exit__(self, *exc):
+        global _rec
+        _rec = None
+        return False
+
+
 def check(rc, what=""):
     if rc < 0:
         msg = load().lpg_last_error()

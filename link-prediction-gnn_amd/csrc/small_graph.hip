@@ -25,6 +25,8 @@
 // dinv[row] * dinv[col] (PyG gcn_norm with unit edge weights) is applied as a column pre-scale and a row scale.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "lpg_common.hpp"
 
 namespace {
@@ -583,4 +585,63 @@ LPG_EXPORT int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P
   hipLaunchKernelGGL(sg_readout_kernel, dim3(grid_for(B * 64)), dim3(kBlock), 0, as_stream(stream), ya, yr,
                      static_cast<int>(P), static_cast<int>(C), na, nr, idx, static_cast<int>(B), w, b0, out, err_flag);
   return check_launch("small_readout");
+}
+
+// ---- the whole small-graph scoring forward as ONE call ------------------------------------------------------------
+// A forward on fb-pages-food is six launches of ~5-12 us; enqueued one ctypes call at a time the host spends 150 us
+// on them (argument marshalling, tensor bookkeeping, one call per kernel).  The host mirror therefore prepares an
+// ARGUMENT BLOCK once per (model, graph, candidate set): the launches of the forward, in order, as int64 words
+//     { op, a_0, ..., a_{k-1} }  per launch,  op in {1: lpg_embedding_graphnorm_f32 (12 words),
+//     2: lpg_small_linear_t_f32 (27), 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23)},
+// a_i = the entry point's i-th argument (pointers and integers as they are, `float eps` as the bit pattern of a
+// double), the trailing `stream` argument left out.  lpg_twowl_forward_small walks the block and enqueues every
+// launch on `stream` through the very same entry points (same checks, same kernels, same results as calling them
+// one by one).
+namespace {
+template <typename T> inline T* wp(int64_t v) { return reinterpret_cast<T*>(static_cast<intptr_t>(v)); }
+inline float wf(int64_t v) {
+  double d;
+  memcpy(&d, &v, sizeof(d));
+  return static_cast<float>(d);
+}
+}  // namespace
+
+LPG_EXPORT int lpg_twowl_forward_small(const int64_t* block, int64_t n_words, void* stream) {
+  LPG_REQUIRE(block && n_words >= 0, "twowl_forward_small: null block");
+  int64_t i = 0;
+  while (i < n_words) {
+    const int64_t op = block[i];
+    const int64_t* a = block + i + 1;
+    const int64_t need = op == 1 ? 12 : op == 2 ? 27 : op == 3 ? 20 : op == 4 ? 23 : -1;
+    LPG_REQUIRE(need > 0 && i + 1 + need <= n_words, "twowl_forward_small: malformed block at word %lld (op %lld)",
+                (long long)i, (long long)op);
+    int rc = LPG_OK;
+    if (op == 1) {
+      rc = lpg_embedding_graphnorm_f32(wp<const float>(a[0]), a[1], a[2], wp<const int64_t>(a[3]), a[4], wp<const float>(a[5]),
+                                       wp<const float>(a[6]), wp<const float>(a[7]), wf(a[8]), static_cast<int>(a[9]),
+                                       wp<float>(a[10]), wp<int32_t>(a[11]), stream);
+    } else if (op == 2) {
+      rc = lpg_small_linear_t_f32(wp<const float>(a[0]), wp<const float>(a[1]), wp<const int64_t>(a[2]), static_cast<int>(a[3]),
+                                  a[4], a[5], a[6], wp<const float>(a[7]), wp<const float>(a[8]), a[9], wp<float>(a[10]),
+                                  wp<float>(a[11]), a[12], wp<const double>(a[13]), wp<const float>(a[14]),
+                                  wp<const float>(a[15]), wp<const float>(a[16]), a[17], static_cast<int>(a[18]),
+                                  wp<const double>(a[19]), wp<const float>(a[20]), wp<const float>(a[21]),
+                                  wp<const float>(a[22]), a[23], static_cast<int>(a[24]), wf(a[25]), wp<int32_t>(a[26]), stream);
+    } else if (op == 3) {
+      rc = lpg_small_gcn_f32(a[0], a[1], a[2], a[3], a[4], a[5], wp<const float>(a[6]), wp<const void>(a[7]),
+                             wp<const int64_t>(a[8]), wp<const float>(a[9]), wp<const float>(a[10]), wp<float>(a[11]),
+                             wp<double>(a[12]), wp<const float>(a[13]), wp<const void>(a[14]), wp<const int64_t>(a[15]),
+                             wp<const float>(a[16]), wp<const float>(a[17]), wp<float>(a[18]), wp<double>(a[19]), stream);
+    } else {
+      rc = lpg_small_readout_f32(wp<const float>(a[0]), wp<const float>(a[1]), a[2], a[3], wp<const double>(a[4]),
+                                 wp<const float>(a[5]), wp<const float>(a[6]), wp<const float>(a[7]), a[8],
+                                 static_cast<int>(a[9]), wp<const double>(a[10]), wp<const float>(a[11]),
+                                 wp<const float>(a[12]), wp<const float>(a[13]), a[14], static_cast<int>(a[15]), wf(a[16]),
+                                 wp<const int64_t>(a[17]), a[18], wp<const float>(a[19]), wp<const float>(a[20]),
+                                 wp<float>(a[21]), wp<int32_t>(a[22]), stream);
+    }
+    if (rc != LPG_OK) return rc;
+    i += 1 + need;
+  }
+  return LPG_OK;
 }

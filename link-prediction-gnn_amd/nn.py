@@ -53,6 +53,7 @@ class _GraphCache:
 
 
 graph_cache = _GraphCache()
+SMALL_GRAPH_KERNELS = True      # GCNConv on graphs of <= lpg_small_max_rows() rows takes the small-graph kernels
 
 
 def _forward_only(mod):
@@ -94,6 +95,15 @@ class GCNConv(nn.Module):
             g = edge_index
         else:
             g = graph_cache.get(edge_index, edge_weight, x.shape[0], True)
+        n = x.shape[0]
+        if (SMALL_GRAPH_KERNELS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 0 < n <= _ops.small_max_rows()
+                and g.unit_gcn and g.n_rows == n and g.n_cols == n and self.in_channels <= 256):
+            # the reference's own graphs (620 nodes / 4252 tuples) are launch-bound: two launches of the small-graph
+            # kernels (transposed linear; aggregation + bias out of LDS) instead of linear + SpMM + fix-up, also when
+            # the module is called through the reference's own Seq (INTEGRATION.md option A)
+            hT = _ops.small_linear_t(x, self.lin.weight)
+            out, = _ops.small_gcn(n, [(hT, g, self.bias, None, False)])
+            return out.y
         h = self.lin(x)                                   # K5: H = X W^T on the fp32 matrix cores
         return g.spmm(h, bias=self.bias)                  # K3+K4: A_hat @ H + b, one fused kernel
 

@@ -466,8 +466,9 @@ class Deferred:
         if self.part is None:
             return [0, 0, 0, 0, 1, 0]
         nm = self.norm
-        return [_ptr(self.part), _ptr(_c(nm.weight, torch.float32)), _ptr(_c(nm.bias, torch.float32)),
-                _ptr(_c(nm.mean_scale, torch.float32)), self.part.shape[0], int(self.relu)]
+        w, b, ms = _c(nm.weight, torch.float32), _c(nm.bias, torch.float32), _c(nm.mean_scale, torch.float32)
+        _lib.keepalive(self.part, w, b, ms)
+        return [_ptr(self.part), _ptr(w), _ptr(b), _ptr(ms), self.part.shape[0], int(self.relu)]
 
     @property
     def eps(self):
@@ -493,10 +494,10 @@ def embedding_graph_norm(table, idx, weight, bias, mean_scale, eps=1e-5, relu=Fa
     idx = _c(idx.reshape(-1), torch.int64)
     n, d = idx.numel(), table.shape[1]
     out = torch.empty((n, d), dtype=torch.float32, device=table.device)
-    _lib.check(lib.lpg_embedding_graphnorm_f32(_ptr(table), table.shape[0], d, _ptr(idx), n,
-                                               _ptr(_c(weight, torch.float32)), _ptr(_c(bias, torch.float32)),
-                                               _ptr(_c(mean_scale, torch.float32)), float(eps), int(relu), _ptr(out),
-                                               _ptr(err_flag(table.device)), _stream()), "embedding_graphnorm")
+    weight, bias, mean_scale = _c(weight, torch.float32), _c(bias, torch.float32), _c(mean_scale, torch.float32)
+    _lib.keepalive(table, idx, weight, bias, mean_scale, out)
+    _lib.call("lpg_embedding_graphnorm_f32", _ptr(table), table.shape[0], d, _ptr(idx), n, _ptr(weight), _ptr(bias),
+              _ptr(mean_scale), float(eps), int(relu), _ptr(out), _ptr(err_flag(table.device)), _stream())
     return out
 
 
@@ -525,9 +526,9 @@ def small_linear_t(xa, weight, weight2=None, xb=None, pos=None):
     hT = torch.empty((m, ldt), dtype=torch.float32, device=ya.device)
     h2T = torch.empty((m, ldt), dtype=torch.float32, device=ya.device) if weight2 is not None else None
     nb = xb.args() if xb is not None else Deferred(None).args()
-    _lib.check(lib.lpg_small_linear_t_f32(_ptr(ya), _ptr(yb), _ptr(pos), mode, n_src, n, k, _ptr(weight), _ptr(weight2),
-                                          m, _ptr(hT), _ptr(h2T), ldt, *xa.args(), *nb, xa.eps,
-                                          _ptr(err_flag(ya.device)), _stream()), "small_linear_t")
+    _lib.keepalive(ya, yb, pos, weight, weight2, hT, h2T)
+    _lib.call("lpg_small_linear_t_f32", _ptr(ya), _ptr(yb), _ptr(pos), mode, n_src, n, k, _ptr(weight), _ptr(weight2),
+              m, _ptr(hT), _ptr(h2T), ldt, *xa.args(), *nb, xa.eps, _ptr(err_flag(ya.device)), _stream())
     return (hT, h2T) if weight2 is not None else hT
 
 
@@ -547,11 +548,13 @@ def small_gcn(n, sides):
         y = torch.empty((n, c), dtype=torch.float32, device=hT.device)
         part = torch.empty((rb, 2, c), dtype=torch.float64, device=hT.device)
         outs.append(Deferred(y, part, norm, relu))
-        args += [_ptr(hT), _ptr(g.small_pack(rb)), _ptr(g.rowptr), _ptr(g.dinv), _ptr(_c(b, torch.float32)), _ptr(y),
-                 _ptr(part)]
+        b = _c(b, torch.float32)
+        pack = g.small_pack(rb)
+        _lib.keepalive(hT, pack, g.rowptr, g.dinv, b, y, part)
+        args += [_ptr(hT), _ptr(pack), _ptr(g.rowptr), _ptr(g.dinv), _ptr(b), _ptr(y), _ptr(part)]
     if len(sides) == 1:
         args += [0] * 7
-    _lib.check(lib.lpg_small_gcn_f32(n, c, ldt, c, rb, e_cap, *args, _stream()), "small_gcn")
+    _lib.call("lpg_small_gcn_f32", n, c, ldt, c, rb, e_cap, *args, _stream())
     return outs
 
 
@@ -566,9 +569,10 @@ def small_readout(a, r, idx, w, b):
     B = idx.numel() // 2
     out = torch.empty((B, 1), dtype=torch.float32, device=ya.device)
     nr = r.args() if r is not None else Deferred(None).args()
-    _lib.check(lib.lpg_small_readout_f32(_ptr(ya), _ptr(yr), ya.shape[0], ya.shape[1], *a.args(), *nr, a.eps, _ptr(idx),
-                                         B, _ptr(_c(w.reshape(-1), torch.float32)), _ptr(_c(b, torch.float32)),
-                                         _ptr(out), _ptr(err_flag(ya.device)), _stream()), "small_readout")
+    w, b = _c(w.reshape(-1), torch.float32), _c(b, torch.float32)
+    _lib.keepalive(ya, yr, idx, w, b, out)
+    _lib.call("lpg_small_readout_f32", _ptr(ya), _ptr(yr), ya.shape[0], ya.shape[1], *a.args(), *nr, a.eps, _ptr(idx),
+              B, _ptr(w), _ptr(b), _ptr(out), _ptr(err_flag(ya.device)), _stream())
     return out
 
 

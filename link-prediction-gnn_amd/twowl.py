@@ -9,9 +9,11 @@ weights trained with the reference load unchanged.  Eval-mode forward only.
 """
 import os
 
+import numpy as np
 import torch
 from torch import nn
 
+from . import _lib
 from . import ops as _ops
 from .nn import GCNConv, GraphNorm, _forward_only, graph_cache
 from .torch_scatter import scatter_add
@@ -81,6 +83,21 @@ class Seq(nn.Module):
         return out if add_to is None else out + add_to
 
 
+class _SmallPlan:
+    """the small-graph forward's launches as an argument block for lpg_twowl_forward_small (include/lpg_hip.h), recorded
+    on the first forward over a given (inputs, parameters) and replayed by ONE host call afterwards"""
+
+    def __init__(self, key, words, keep, out_shape, device):
+        self.key, self.keep, self.out_shape, self.device = key, keep, out_shape, device
+        self.block = np.asarray(words, dtype=np.int64)
+        self.ptr, self.n_words = int(self.block.ctypes.data), int(self.block.size)
+        self.out_word = self.n_words - 2          # the readout is the last launch; `out` is its 22nd of 23 words
+
+
+def _tkey(t):
+    return (t.data_ptr(), t._version, t.shape[0])
+
+
 class LocalWLNet(nn.Module):
     """TwoWL/model/model.py:8-84 (degree-embedding variant, use_node_feat=False)."""
 
@@ -97,6 +114,7 @@ class LocalWLNet(nn.Module):
                         nn.ReLU(inplace=True) if act else nn.Identity()])
 
         self.max_x, self.use_node_feat, self.node_feat = max_x, use_node_feat, node_feat
+        self._plan, self._plan_params = None, []
         self.emb = nn.Sequential(nn.Embedding(max_x + 1, channels_1wl), GraphNorm(channels_1wl),
                                  nn.Dropout(p=dp_emb, inplace=True))
         self.conv1s = nn.ModuleList([relu_conv(channels_1wl, channels_1wl, dp_1wl0, act0) for _ in range(depth1 - 1)]
@@ -105,15 +123,46 @@ class LocalWLNet(nn.Module):
         self.conv2s_r = nn.ModuleList([relu_conv(channels_2wl, channels_2wl, dp_2wl, True) for _ in range(depth2)])
         self.pred = nn.Linear(channels_2wl, 1)
 
+    def _apply(self, fn, *args, **kwargs):
+        self._plan = None                     # .to() / .float() replace the parameter tensors
+        return super()._apply(fn, *args, **kwargs)
+
+    def invalidate_plans(self):
+        """drop the recorded small-graph launch block (needed only after replacing Parameter OBJECTS of a submodule by
+        hand; in-place updates -- optimizers, load_state_dict, .to() -- are noticed by themselves)"""
+        self._plan = None
+
     def forward(self, x, edge1, pos, idx=None, ei2=None, test=False):
         _forward_only(self)
+        plan = getattr(self, "_plan", None)
+        if plan is not None and _SMALL_PATH and idx is not None and ei2 is not None:
+            # steady state of a scoring loop (TwoWL/model/train.py:54-60 calls the same tensors every time): the whole
+            # forward is one host call over the recorded argument block
+            key = (_tkey(x), _tkey(edge1) if torch.is_tensor(edge1) else id(edge1), _tkey(pos), _tkey(idx), _tkey(ei2),
+                   tuple([p._version for p in self._plan_params]))
+            if key == plan.key:
+                out = torch.empty(plan.out_shape, dtype=torch.float32, device=plan.device)
+                plan.block[plan.out_word] = out.data_ptr()
+                _lib.check(_lib.load().lpg_twowl_forward_small(plan.ptr, plan.n_words, _ops._stream()), "twowl_forward_small")
+                return out
         # K8: reverse(ei2) is never materialised -- the flips are folded into the two CSR builds
         # (edge2 = (flip(e0), e1), edge2_r = (e0, flip(e1))), memoised on ei2's identity.
         P = pos.shape[0]
         edge2 = graph_cache.get(ei2, None, P, True, flip=1)
         edge2_r = graph_cache.get(ei2, None, P, True, flip=2)
         if self._small_graph_ok(x, edge1, P):
-            return self._forward_small(x, edge1, pos, idx, edge2, edge2_r)
+            if idx is None or ei2 is None or torch.cuda.is_current_stream_capturing():
+                return self._forward_small(x, edge1, pos, idx, edge2, edge2_r)
+            # first forward over these inputs: run the launches one by one, recording them (and checking the indices:
+            # the recorded block is only replayed for the same tensors at the same versions, so once is enough)
+            self._plan_params = [p for p in self.parameters()]
+            key = (_tkey(x), _tkey(edge1) if torch.is_tensor(edge1) else id(edge1), _tkey(pos), _tkey(idx), _tkey(ei2),
+                   tuple([p._version for p in self._plan_params]))
+            with _lib.recording() as rec:
+                out = self._forward_small(x, edge1, pos, idx, edge2, edge2_r)
+            self._plan = _SmallPlan(key, rec["words"], rec["keep"] + [x, edge1, pos, idx, ei2, edge2, edge2_r],
+                                    tuple(out.shape), out.device)
+            return out
         x = _ops.embedding(self.emb[0].weight, x)                      # Embedding(deg)
         x = self.emb[1](x)                                             # GraphNorm (Dropout: eval identity)
         for conv1 in self.conv1s:
@@ -232,7 +281,8 @@ _idx_cache = {}
 @torch.no_grad()
 def test_forward(mod, x, ei, pos1, y_len, ei2):
     """the timed scoring forward of TwoWL/model/train.py:54-60."""
-    mod.eval()
+    if mod.training:
+        mod.eval()
     key = (ei.shape[1], int(y_len), x.device)
     idx = _idx_cache.get(key)
     if idx is None:                                    # the index vector only depends on two sizes: built once

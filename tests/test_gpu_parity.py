@@ -576,12 +576,11 @@ def test_localwl_forward_fb_pages_food(dev, tw, c1, c2, d1, d2):
     (+ ReLU), the pair product, the orientation sum, the readout -- is run on the HIP kernels with the ORACLE's fp64
     input rounded to fp32 and held to TOL = 1e-5 times the magnitude that stage sums (north star: 1e-5 relative).
 
-    Whole forward: the logits are held to the first-order propagation of those per-stage errors through the network
-    (oracle.aggregation.localwl_forward_stages: |W| for linears, the normalised adjacency for aggregations, and for
-    GraphNorm the sensitivities 1/s and |o|/s^2 of y = w o / s + b -- GraphNorm divides by the column's standard
-    deviation, which is what makes the end-to-end error larger than 1e-5 of the logit scale: an aggregation output
-    whose spread s is small against the magnitudes it summed is amplified by |x| / s).  No free constant: the bound
-    is what a forward accurate to 1e-5 per stage can produce, and the measured error must stay below it."""
+    Whole forward, both device paths (small-graph kernels and kernel-per-op): every logit within 1e-5 of the logit
+    scale max|logit| of the fp64 oracle -- the north star's bar taken at the output, no slack factor -- and the AUC
+    identical.  (A worst-case propagation of the per-stage errors through the GraphNorm divisions,
+    oracle.aggregation.localwl_forward_stages()[-1]["bound"], is orders of magnitude above what is measured and is
+    therefore not used as a criterion; the measured error is printed.)"""
     from lpgnn_amd import twowl
     from oracle import aggregation as agg
     mod, x_deg, ei, pred, ei2, pos1 = _localwl_case(tw, c1, c2, d1, d2, dev)
@@ -602,21 +601,21 @@ def test_localwl_forward_fb_pages_food(dev, tw, c1, c2, d1, d2):
             logits = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2))
             again = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), y_len, t(ei2))
         assert logits.shape == (y_len // 2, 1) and torch.equal(logits, again)      # atomic-free: bitwise reproducible
-        want, bound = stages[-1]["out"], stages[-1]["bound"]
+        want = stages[-1]["out"]
         got = _np(logits).astype(np.float64)
-        assert np.all(np.abs(got - want) <= bound), float((np.abs(got - want) / bound).max())
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= TOL * scale, (small, np.abs(got - want).max() / scale)
         y = np.concatenate([np.ones(y_len // 4), np.zeros(y_len // 4)])
         assert abs(agg.auc(y, got) - agg.auc(y, want)) <= 0.002
-    scale = np.abs(want).max() + 1.0
-    print(f"LocalWLNet {c1}/{c2}/{d1}/{d2}: max |logit error| {np.abs(got - want).max():.2e}, propagated bound "
-          f"{bound.max():.2e} = {bound.max() / (TOL * scale):.1f} x (1e-5 x logit scale)")
+        print(f"LocalWLNet {c1}/{c2}/{d1}/{d2} {'small-graph' if small else 'kernel-per-op'} path: max |logit error| "
+              f"{np.abs(got - want).max():.2e} = {np.abs(got - want).max() / scale:.1e} of the logit scale {scale:.1f}")
 
 
 # ------------------------------------------------------------------ small-graph GCN blocks (the launch-bound regime)
 def test_localwl_small_path_matches_generic_path(dev, tw, monkeypatch):
     """the two-launches-per-block path (default for <= 8192 rows) and the kernel-per-op path on the fb-pages-food
-    forward: each within the propagated 1e-5-per-stage bound of the fp64 oracle (see
-    test_localwl_forward_fb_pages_food), hence within twice that bound of each other."""
+    forward: each within 1e-5 of the logit scale of the fp64 oracle (as in test_localwl_forward_fb_pages_food), hence
+    within 2e-5 of it of each other."""
     from lpgnn_amd import twowl
     from oracle import aggregation as agg
     t = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
@@ -631,9 +630,10 @@ def test_localwl_small_path_matches_generic_path(dev, tw, monkeypatch):
         assert not mod._small_graph_ok(t(x_deg), t(ei), pos1.shape[0])
         generic = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), pred.shape[1], t(ei2))
         monkeypatch.setattr(twowl, "_SMALL_PATH", True)
+        scale = np.abs(last["out"]).max()
         for got in (small, generic):
-            assert np.all(np.abs(_np(got).astype(np.float64) - last["out"]) <= last["bound"])
-        assert np.all(np.abs(_np(small).astype(np.float64) - _np(generic)) <= 2 * last["bound"])
+            assert np.abs(_np(got).astype(np.float64) - last["out"]).max() <= TOL * scale
+        assert np.abs(_np(small).astype(np.float64) - _np(generic)).max() <= 2 * TOL * scale
 
 
 @pytest.mark.parametrize("n,k,m", [(620, 256, 32), (4252, 32, 32), (1, 24, 16), (7, 64, 24), (1030, 100, 40),
@@ -1066,6 +1066,61 @@ def test_full_size_headline_instance_properties(dev):
     ops._scatter_plans.clear()
 
 
+def test_small_forward_plan_replay(dev, tw):
+    """LocalWLNet's recorded launch block (lpg_twowl_forward_small, one host call per forward): bit-identical to the
+    one-by-one launches, fresh output tensor per call, re-recorded when a parameter or an input changes in place."""
+    from lpgnn_amd import twowl
+    from oracle import aggregation as agg
+    mod, x_deg, ei, pred, ei2, pos1 = _localwl_case(tw, 256, 32, 1, 1, dev, seed=5)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    xd, eit, p1, e2 = t(x_deg), t(ei), t(pos1), t(ei2)
+    y_len = pred.shape[1]
+    first = twowl.test_forward(mod, xd, eit, p1, y_len, e2)              # records
+    plan = mod._plan
+    assert plan is not None and plan.n_words == (1 + 12) + 2 * (1 + 27) + 2 * (1 + 20) + (1 + 23)
+    second = twowl.test_forward(mod, xd, eit, p1, y_len, e2)             # replays the block
+    third = twowl.test_forward(mod, xd, eit, p1, y_len, e2)
+    assert mod._plan is plan and torch.equal(first, second) and torch.equal(second, third)
+    assert second.data_ptr() != third.data_ptr()                          # a fresh output per call
+    with torch.no_grad():
+        mod.pred.bias.add_(1.0)                                           # in-place update: version bump -> re-record
+    moved = twowl.test_forward(mod, xd, eit, p1, y_len, e2)
+    assert mod._plan is not plan and torch.allclose(moved, first + 1.0, atol=1e-6)
+    idx = ei.shape[1] + np.arange(y_len)
+    want = agg.localwl_forward(mod.export_params(), x_deg, ei, pos1, idx, ei2)
+    assert np.abs(_np(moved) - want).max() <= TOL * np.abs(want).max()
+    plan2 = mod._plan
+    p1b = p1.clone()                                                      # another candidate tensor: another key
+    other = twowl.test_forward(mod, xd, eit, p1b, y_len, e2)
+    assert mod._plan is not plan2 and torch.equal(other, moved)
+    bad = p1.clone()
+    bad[5, 0] = 10_000                                                    # the recording call still checks indices
+    with pytest.raises(IndexError):
+        twowl.test_forward(mod, xd, eit, bad, y_len, e2)
+
+
+def test_gcnconv_module_takes_small_graph_kernels(dev, tw, monkeypatch):
+    """nn.GCNConv called the way the reference's own Seq calls it (TwoWL/model/model.py:92-96: module by module) on a
+    graph of <= 8192 rows: the two small-graph launches, against the kernel-per-op path and the fp64 oracle."""
+    from lpgnn_amd import nn as lnn
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(9)
+    ei = tw["test_ei"].astype(np.int64)
+    x = rng.standard_normal((620, 64)).astype(np.float32)
+    torch.manual_seed(2)
+    conv = lnn.GCNConv(64, 24).to(dev).eval()
+    with torch.no_grad():
+        conv.bias.uniform_(-0.5, 0.5)
+        small = conv(torch.from_numpy(x).to(dev), torch.from_numpy(ei).to(dev))
+        monkeypatch.setattr(lnn, "SMALL_GRAPH_KERNELS", False)
+        generic = conv(torch.from_numpy(x).to(dev), torch.from_numpy(ei).to(dev))
+    w, b = _np(conv.lin.weight).astype(np.float64), _np(conv.bias).astype(np.float64)
+    want = agg.gcn_conv(x.astype(np.float64), ei, w, b)
+    mag = agg.gcn_conv(np.abs(x).astype(np.float64), ei, np.abs(w), np.abs(b))
+    for got in (small, generic):
+        assert np.all(np.abs(_np(got) - want) <= 2 * TOL * mag)          # two stages (linear, aggregation), TOL each
+
+
 def test_captured_forward_matches_eager(dev, tw):
     """hipGraph replay of the scoring forward == the eager forward, bit for bit."""
     from lpgnn_amd import twowl
@@ -1428,8 +1483,8 @@ def test_trained_model_auc_parity_fb_pages_food(dev, golden_dir):
     """north-star AUC clause as kernel-substitution parity at a MEANINGFUL AUC: train LocalWLNet on
     the seeded fb-pages-food split with a plain-PyTorch fp32 reference of the model (autograd), then
     score the test split with (a) that torch reference and (b) the HIP kernels on the same weights:
-    both within the propagated 1e-5-per-stage bound of the fp64 oracle on those weights (hence within twice that of
-    each other), AUC within +-0.002 (and well above chance)."""
+    both within 1e-5 of the logit scale of the fp64 oracle on those weights (hence within 2e-5 of it of each other),
+    AUC within +-0.002 (and well above chance)."""
     from lpgnn_amd import data, twowl
     from oracle import aggregation as agg
     from tests import torch_reference as tref
@@ -1448,10 +1503,11 @@ def test_trained_model_auc_parity_fb_pages_food(dev, golden_dir):
     auc_ref, auc_got = agg.auc(labels, _np(ref).reshape(-1)), agg.auc(labels, _np(got).reshape(-1))
     npi = lambda a: _np(a).astype(np.int64)
     last = agg.localwl_forward_stages(mod.export_params(), npi(x), npi(ei), npi(pos1), npi(idx), npi(ei2), tol=TOL)[-1]
+    scale = np.abs(last["out"]).max()
     for name, out in (("HIP kernels", got), ("torch fp32 reference", ref)):
-        err = np.abs(_np(out).astype(np.float64) - last["out"])
-        assert np.all(err <= last["bound"]), (name, float((err / last["bound"]).max()))
-    assert np.all(np.abs(_np(got).astype(np.float64) - _np(ref)) <= 2 * last["bound"])
+        err = np.abs(_np(out).astype(np.float64) - last["out"]).max()
+        assert err <= TOL * scale, (name, err / scale)
+    assert np.abs(_np(got).astype(np.float64) - _np(ref)).max() <= 2 * TOL * scale
     assert abs(auc_ref - auc_got) <= 0.002
     assert auc_ref > 0.75, auc_ref            # the recorded reference runs span 0.79-0.89 (unseeded, 1000 epochs)
     print(f"fb-pages-food test AUC: torch reference {auc_ref:.4f}, HIP kernels {auc_got:.4f}")
