@@ -313,21 +313,26 @@ int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, int64_t n_no
  * trigger in either visiting order.  cap_policy 0: such pairs come back with n = 0 and the caller
  * supplies the node list (replay != 0 makes the kernel take nodes/n_nodes as INPUT -- how tests
  * replay the reference's own lists); cap_policy 1: the kernel follows the same branch with a
- * counter-based hash of (seed, b) in place of the RNG (visiting order, kept neighbours).
+ * counter-based hash of (seed, u, v) in place of the RNG (visiting order, kept neighbours).
  * tags[b, i] = DRNL tag (raw, before the global compaction); adjacency is returned as a bit
  * matrix adj_bits[b, i, w] (uint32 words, MAXN/32 words per row), target entries cleared.
  * tag_present (optional, caller-zeroed, LPG_SEAL_TAG_BOUND + 1 bytes): byte [tag] is set for every tag the
  * batch uses -- the presence table of the global tag compaction [SEAL/config/subgraph.py:84-101].
  * hub_index / hub_bits (optional, both or neither): hub_index[node] (int32, n_graph_nodes entries) = the node's row in
  * the hub bit matrix or -1; hub_bits[row * hub_words + (c >> 5)] bit (c & 31) = hubs row and c are adjacent.  Nodes
- * with more than 256 neighbours should be hubs: their mutual adjacency is then one load instead of a binary search. */
+ * with more than 256 neighbours should be hubs: their mutual adjacency is then one load instead of a binary search.
+ * One launch, two kinds of workgroup: a pair whose two neighbour lists hold <= 62 entries together (n <= 64, the
+ * cap cannot fire: most of a batch) is handled by ONE 64-lane wave (two pairs per workgroup, no workgroup barrier); every
+ * other pair by the 128 threads of a workgroup that owns 8 consecutive pairs.  Same outputs bit for bit either way;
+ * option "seal_pair_small" = 0 (or replay) gives every pair a 128-thread workgroup. */
 #define LPG_SEAL_MAXN 128
 #define LPG_SEAL_TAG_BOUND (1 + 127 + 127 * 127)
 int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
                        const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
-                       int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits,
-                       uint8_t* capped, uint8_t* tag_present, const int32_t* hub_index,
-                       const uint32_t* hub_bits, int64_t hub_words, int32_t* err_flag, void* stream);
+                       int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes,
+                       int32_t* tags, uint32_t* adj_bits, uint8_t* capped, uint8_t* tag_present,
+                       const int32_t* hub_index, const uint32_t* hub_bits, int64_t hub_words,
+                       int32_t* err_flag, void* stream);
 /* Block-diagonal CSR of A~ = A + I over a batch, D^-1 = 1/rowsum(A~), and
  * X = [onehot(tag_map[tag], T) || emb[node]]  [SEAL/config/data.py:94-140].
  * node_off[B+1] = exclusive scan of n_nodes (host-computed or torch.cumsum);

@@ -18,6 +18,8 @@ using namespace lpg;
 constexpr int MAXN = LPG_SEAL_MAXN;  // 128 >= the reference's max_neighbors = 100
 constexpr int WORDS = MAXN / 32;
 constexpr int kSealBlock = 128;      // thread i <-> subgraph vertex i
+constexpr int kDeferGroup = 8;       // consecutive pairs a 128-thread workgroup owns in the fused launch (it handles those no wave can)
+__device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ bool row_has(const int32_t* __restrict__ row, int len, int32_t key) {
   int lo = 0, hi = len;
@@ -108,29 +110,298 @@ __device__ ListPlan truncated_list(int32_t node, int64_t deg, int m, uint64_t h)
   return L;
 }
 
+// ---- small pairs: ONE WAVE per candidate pair ---------------------------------------------------------------------
+// 60 % of the candidate pairs of a collab-shaped batch have fewer than 8 subgraph vertices, 94 % fewer than 64; in
+// the 128-thread workgroup above such a pair is ~6 us of barriers and dependent round trips with most threads idle.
+// Here a pair whose two neighbour lists hold at most 62 entries together (so n <= 64 and the reference's cap cannot
+// fire) is handled by one 64-lane wave without a single workgroup barrier: lane i <-> subgraph vertex i, an adjacency
+// row is ONE 64-bit word, the DRNL sweeps are wave-wide OR-reductions.  Same node order, adjacency bits and tags as
+// the workgroup path, bit for bit (tests run both on the same pairs).  Every other pair (long lists, the cap) is taken
+// by a 128-thread workgroup of the SAME launch (seal_subgraph_kernel, fused mode): the two kinds of work overlap, the
+// long hub-rich pairs start first.
+constexpr int kWaveN = 64;                  // vertices a wave handles: lane i <-> vertex i
+
+struct WavePair {
+  int32_t nodes[kWaveN];
+  unsigned long long adj[kWaveN];
+  int pre[kWaveN + 1];
+  int64_t rbase[kWaveN];
+  int rdeg[kWaveN];
+  int big[kWaveN];
+};
+
+__device__ __forceinline__ void wave_lds_sync() {       // LDS written by some lanes of the wave, read by others
+  __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {   // OR over the 64 lanes, result in every lane
+  uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    lo |= __shfl_xor(lo, o, 64);
+    hi |= __shfl_xor(hi, o, 64);
+  }
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+// the rule both kinds of workgroup apply to decide who owns a pair (targets already range-checked)
+__device__ __forceinline__ bool pair_fits_wave(int hop, int max_nb, int32_t u, int32_t v, int64_t du, int64_t dv) {
+  const int size0 = (u == v) ? 1 : 2;
+  return hop == 0 || (size0 + du + dv < max_nb && du + dv <= kWaveN - 2);
+}
+
+__device__ __forceinline__ void wave_pair(
+    WavePair& L, int64_t b, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_graph,
+    const int64_t* __restrict__ pairs, int hop, int max_nb, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
+    int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag,
+    uint8_t* __restrict__ tag_present, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
+    int hub_words) {
+  const int lane = threadIdx.x & 63;
+  const int64_t u64 = pairs[2 * b], v64 = pairs[2 * b + 1];
+  if (u64 < 0 || u64 >= n_graph || v64 < 0 || v64 >= n_graph) {
+    if (lane == 0) { flag_error(err_flag, LPG_F_INDEX_RANGE); n_out[b] = 0; capped_out[b] = 0; }
+    return;
+  }
+  const int32_t u = static_cast<int32_t>(u64), v = static_cast<int32_t>(v64);
+  const int64_t bu = rowptr[u], du = rowptr[u + 1] - bu;
+  const int64_t bv = rowptr[v], dv = rowptr[v + 1] - bv;
+  const int64_t dv_used = (u == v) ? 0 : dv;             // the second list is not walked when the targets coincide
+  if (!pair_fits_wave(hop, max_nb, u, v, du, dv)) return;        // a 128-thread workgroup of this launch owns it
+  // ---- node set {u, v} U N(u) U N(v): duplicates dropped (first occurrence kept), the rest ascending
+  int n = 2;
+  L.adj[lane] = 0ull;
+  if (hop >= 1) {
+    const int nc = static_cast<int>(du + dv_used);
+    int32_t x = -1;
+    if (lane < nc) {
+      x = lane < du ? col[bu + lane] : col[bv + (lane - du)];
+      if (x == u || x == v) x = -1;
+    }
+    bool keep = x >= 0;
+    for (int j = 0; j < nc; ++j) {
+      const int32_t y = __shfl(x, j, 64);
+      if (j < lane && y == x) keep = false;
+    }
+    const int32_t xs = keep ? x : 0x7FFFFFFF;
+    int rank = 0;
+    for (int j = 0; j < nc; ++j) rank += __shfl(xs, j, 64) < x;
+    if (keep) L.nodes[2 + rank] = x;
+    n = 2 + __popcll(__ballot(keep));
+  }
+  if (lane == 0) { L.nodes[0] = u; L.nodes[1] = v; }
+  wave_lds_sync();
+  // ---- induced adjacency (one word per row), exactly the rules of seal_subgraph_kernel
+  bool isbig = false;
+  int mylen = 0;
+  if (lane < n) {
+    const int32_t a = L.nodes[lane];
+    const int64_t ba = rowptr[a];
+    const int da = static_cast<int>(rowptr[a + 1] - ba);
+    L.rbase[lane] = ba;
+    L.rdeg[lane] = da;
+    isbig = da > 256;
+    mylen = isbig ? 0 : da;
+  }
+  const uint64_t bigmask = __ballot(isbig);
+  const int nbig = __popcll(bigmask);
+  if (isbig) L.big[__popcll(bigmask & ((uint64_t(1) << lane) - 1))] = lane;
+  int inc = mylen;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  L.pre[lane] = inc - mylen;
+  const int total = __shfl(inc, 63, 64);
+  if (lane == 0) L.pre[kWaveN] = total;
+  wave_lds_sync();
+  constexpr int IT = 4;
+  for (int p0 = IT * lane; p0 < total; p0 += IT * 64) {
+    int32_t x[IT];
+    uint32_t rows = 0;
+    {
+      int lo = 0, hi = n;                                // last row i with pre[i] <= p0
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (L.pre[mid] <= p0) lo = mid; else hi = mid;
+      }
+      int rr = lo;
+#pragma unroll
+      for (int q = 0; q < IT; ++q) {
+        const int p = p0 + q;
+        while (rr + 1 < n && L.pre[rr + 1] <= p) ++rr;
+        x[q] = p < total ? col[L.rbase[rr] + (p - L.pre[rr])] : -1;
+        rows |= static_cast<uint32_t>(rr) << (8 * q);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+      const int i = static_cast<int>((rows >> (8 * q)) & 0xFFu);
+      const int32_t xv = x[q];
+      if (xv < 0) continue;
+      const unsigned long long ibit = 1ull << i;
+      if (xv == u && i != 1) { atomicOr(&L.adj[i], 1ull); atomicOr(&L.adj[0], ibit); }
+      if (xv == v && i != 0) { atomicOr(&L.adj[i], 2ull); atomicOr(&L.adj[1], ibit); }
+      if (xv != u && xv != v) {
+        int lo = 2, hi = n;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (L.nodes[mid] < xv) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n && L.nodes[lo] == xv) {
+          atomicOr(&L.adj[i], 1ull << lo);
+          atomicOr(&L.adj[lo], ibit);
+        }
+      }
+    }
+  }
+  // rows with more than 256 neighbours are not streamed: symmetry filled them from the other side; what is left are
+  // the entries between two such rows -- the hub bit matrix when the graph has one, else a binary search
+  for (int p = lane; p < nbig * nbig; p += 64) {
+    const int a = p / nbig, b2 = p - a * nbig;
+    if (a > b2) continue;
+    const int i = L.big[a], j = L.big[b2];
+    if ((i == 0 && j == 1) || (i == 1 && j == 0)) continue;
+    bool hit;
+    const int ia = hub_index ? hub_index[L.nodes[i]] : -1, ib = hub_index ? hub_index[L.nodes[j]] : -1;
+    if (ia >= 0 && ib >= 0) {
+      hit = (hub_bits[static_cast<int64_t>(ia) * hub_words + (ib >> 5)] >> (ib & 31)) & 1u;
+    } else {
+      hit = row_has(col + L.rbase[i], L.rdeg[i], L.nodes[j]);
+    }
+    if (hit) { atomicOr(&L.adj[i], 1ull << j); atomicOr(&L.adj[j], 1ull << i); }
+  }
+  wave_lds_sync();
+  // ---- DRNL (utils.py:35-54): both BFS sweeps as wave-wide OR-reductions of the frontier's rows
+  const uint64_t row = lane < n ? L.adj[lane] : 0ull;
+  uint64_t vis0 = 1ull, fr0 = 1ull, vis1 = 2ull, fr1 = 2ull;
+  int d0 = lane == 0 ? 0 : -1, d1 = lane == 1 ? 0 : -1;
+  for (int level = 1; level <= n; ++level) {
+    const bool in0 = (fr0 >> lane) & 1ull, in1 = (fr1 >> lane) & 1ull;
+    const uint64_t f0 = wave_or64(in0 ? row : 0ull) & ~vis0, f1 = wave_or64(in1 ? row : 0ull) & ~vis1;
+    if ((f0 >> lane) & 1ull) d0 = level;
+    if ((f1 >> lane) & 1ull) d1 = level;
+    vis0 |= f0; vis1 |= f1; fr0 = f0; fr1 = f1;
+    if (!(f0 | f1)) break;
+  }
+  int tag = -1, nd = -1;
+  if (lane < n) {
+    nd = L.nodes[lane];
+    if (lane < 2) {
+      tag = 1;
+    } else if (d0 < 0 || d1 < 0) {
+      tag = 0;
+    } else {
+      const int d = d0 + d1, dv2 = d >> 1, md = d & 1;
+      tag = 1 + (d0 < d1 ? d0 : d1) + dv2 * (dv2 + md - 1);
+    }
+  }
+  tags_out[b * MAXN + lane] = tag;
+  tags_out[b * MAXN + 64 + lane] = -1;
+  nodes_out[b * MAXN + lane] = nd;
+  nodes_out[b * MAXN + 64 + lane] = -1;
+  if (tag_present && tag >= 0) tag_present[tag] = 1;
+  uint4* ao = reinterpret_cast<uint4*>(adj_out + b * MAXN * WORDS);
+  ao[lane] = make_uint4(static_cast<uint32_t>(row), static_cast<uint32_t>(row >> 32), 0u, 0u);
+  ao[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+  if (lane == 0) { n_out[b] = n; capped_out[b] = 0; }
+}
+
+// LDS of a 128-thread team working on one pair
+struct BigPairLds {
+  int32_t cand[2 * MAXN];
+  int32_t nodes[MAXN];
+  uint32_t adj[MAXN][WORDS];
+  int dist0[MAXN], dist1[MAXN];
+  uint32_t vis[2 * WORDS], fr[2 * WORDS], nx[2 * WORDS];
+  int s_n, s_capped, s_cnt[2], s_nbig, s_search;
+  ListPlan s_list[2];
+  int64_t rbase[MAXN];                  // per subgraph vertex: its neighbour list in the big graph
+  int rdeg[MAXN];
+  int big[MAXN];                        // rows whose list is searched instead of streamed
+  int pre[MAXN + 2];                    // exclusive prefix of the streamed rows' list lengths
+  uint32_t member[128];                 // 4096-bit hash filter of the subgraph's vertices (no false negatives)
+};
+
 // latency-bound: 8 waves per SIMD (64 VGPRs, 6 of them spilled) beat 6 waves with none
 __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void seal_subgraph_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_graph, const int64_t* __restrict__ pairs,
     int64_t B, int hop, int max_nb, int replay, int cap_policy, uint64_t seed, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
     int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag,
     uint8_t* __restrict__ tag_present, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
-    int hub_words) {
-  __shared__ int32_t cand[2 * MAXN];
-  __shared__ int32_t nodes[MAXN];
-  __shared__ uint32_t adj[MAXN][WORDS];
-  __shared__ int dist0[MAXN], dist1[MAXN];
-  __shared__ uint32_t vis[2 * WORDS], fr[2 * WORDS], nx[2 * WORDS];
-  __shared__ int s_n, s_capped, s_cnt[2], s_nbig, s_search;
-  __shared__ ListPlan s_list[2];
-  __shared__ int64_t rbase[MAXN];                  // per subgraph vertex: its neighbour list in the big graph
-  __shared__ int rdeg[MAXN];
-  __shared__ int big[MAXN];                        // rows whose list is searched instead of streamed
-  __shared__ int pre[MAXN + 2];                    // exclusive prefix of the streamed rows' list lengths
-  __shared__ uint32_t member[128];                 // 4096-bit hash filter of the subgraph's vertices (no false negatives)
+    int hub_words, int fused) {
+  // fused == 0: workgroup w takes pairs w, w + gridDim.x, ... with all 128 threads (every pair; replayed node lists).
+  // fused != 0: ONE launch, two kinds of workgroup.  The first ceil(B / kDeferGroup) workgroups each own kDeferGroup
+  // consecutive pairs and handle, with all 128 threads, those that do not fit a wave (long neighbour lists, the cap);
+  // the workgroups after them are two independent waves, one small pair each (wave_pair above).  The heavy pairs are
+  // dispatched first and overlap with the stream of small ones.  (First tried: a wave kernel that queued the rest for
+  // a second launch popping an atomic counter -- 100 K same-address atomics take 4-6 ms on this chip, ~50 ns each,
+  // whichever side pushes or pops; and two back-to-back launches serialise the heavy tail behind the small pairs.)
+  // a workgroup is either two waves (wave_pair) or one 128-thread team: the two sets of LDS arrays share storage
+  // (10 KB per workgroup keeps 16 workgroups = 8 waves per SIMD on a CU's 160 KB)
+  __shared__ union {
+    WavePair wave[kSealBlock / 64];
+    BigPairLds team;
+  } lds;
+  WavePair* const wp = lds.wave;
+  __shared__ uint8_t s_defer[kDeferGroup];
+  const int64_t n_groups = fused ? ceil_div_dev(B, kDeferGroup) : 0;
+  if (fused && static_cast<int64_t>(blockIdx.x) >= n_groups) {
+    const int64_t bw = (static_cast<int64_t>(blockIdx.x) - n_groups) * (kSealBlock / 64) + (threadIdx.x >> 6);
+    if (bw < B)                                          // wave-uniform; wave_pair has no workgroup barrier
+      wave_pair(wp[threadIdx.x >> 6], bw, rowptr, col, n_graph, pairs, hop, max_nb, nodes_out, n_out, tags_out, adj_out,
+                capped_out, err_flag, tag_present, hub_index, hub_bits, hub_words);
+    return;
+  }
+  int32_t (&cand)[2 * MAXN] = lds.team.cand;
+  int32_t (&nodes)[MAXN] = lds.team.nodes;
+  uint32_t (&adj)[MAXN][WORDS] = lds.team.adj;
+  int (&dist0)[MAXN] = lds.team.dist0;
+  int (&dist1)[MAXN] = lds.team.dist1;
+  uint32_t (&vis)[2 * WORDS] = lds.team.vis;
+  uint32_t (&fr)[2 * WORDS] = lds.team.fr;
+  uint32_t (&nx)[2 * WORDS] = lds.team.nx;
+  int& s_n = lds.team.s_n;
+  int& s_capped = lds.team.s_capped;
+  int (&s_cnt)[2] = lds.team.s_cnt;
+  int& s_nbig = lds.team.s_nbig;
+  int& s_search = lds.team.s_search;
+  ListPlan (&s_list)[2] = lds.team.s_list;
+  int64_t (&rbase)[MAXN] = lds.team.rbase;
+  int (&rdeg)[MAXN] = lds.team.rdeg;
+  int (&big)[MAXN] = lds.team.big;
+  int (&pre)[MAXN + 2] = lds.team.pre;
+  uint32_t (&member)[128] = lds.team.member;
   const int t = threadIdx.x;
 
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int64_t iter = 0;; ++iter) {
     __syncthreads();
+    int64_t b;
+    if (fused) {
+      if (iter == 0) {                                   // who owns my kDeferGroup pairs: one thread per pair, in parallel
+        if (t < kDeferGroup) {
+          const int64_t bq = static_cast<int64_t>(blockIdx.x) * kDeferGroup + t;
+          bool mine = false;
+          if (bq < B) {
+            const int64_t uq = pairs[2 * bq], vq = pairs[2 * bq + 1];
+            if (uq >= 0 && uq < n_graph && vq >= 0 && vq < n_graph)       // (an out-of-range pair is flagged by its wave)
+              mine = !pair_fits_wave(hop, max_nb, static_cast<int32_t>(uq), static_cast<int32_t>(vq),
+                                     rowptr[uq + 1] - rowptr[uq], rowptr[vq + 1] - rowptr[vq]);
+          }
+          s_defer[t] = mine;
+        }
+        __syncthreads();
+      }
+      if (iter >= kDeferGroup) break;
+      b = static_cast<int64_t>(blockIdx.x) * kDeferGroup + iter;
+      if (b >= B) break;
+      if (!s_defer[iter]) continue;                      // block-uniform
+    } else {
+      b = static_cast<int64_t>(blockIdx.x) + iter * gridDim.x;
+      if (b >= B) break;
+    }
     const int64_t u64 = pairs[2 * b], v64 = pairs[2 * b + 1];
     const bool bad = u64 < 0 || u64 >= n_graph || v64 < 0 || v64 >= n_graph;
     if (bad) {                                       // block-uniform
@@ -906,13 +1177,17 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   LPG_REQUIRE(max_neighbors >= 2 && max_neighbors <= MAXN, "seal_subgraphs: max_neighbors must be in [2, %d]", MAXN);
   if (B == 0) return LPG_OK;
   LPG_REQUIRE(adj_rowptr && pairs && nodes && n_nodes && tags && adj_bits && capped, "seal_subgraphs: null pointer");
-  // a workgroup per pair, NOT a persistent grid striding the list: the cost of a pair spans 10x (hub-rich subgraphs) and
-  // a static share of ~24 pairs per workgroup left the chip waiting for the unluckiest one (100 K collab-shaped pairs:
-  // 0.755 ms with 4096 workgroups, 0.581 ms with one per pair -- the hardware dispatcher is the work queue)
-  const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
-  hipLaunchKernelGGL(seal_subgraph_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), adj_rowptr, adj_col,
+  hipStream_t st = as_stream(stream);
+  const int32_t* hidx = hub_bits ? hub_index : nullptr;
+  const bool fused = !replay && options().seal_pair_small && B < (int64_t(1) << 30) &&
+                     reinterpret_cast<uintptr_t>(adj_bits) % 16 == 0;
+  // fused: ceil(B / 8) workgroups for the pairs that need 128 threads, then one WAVE per pair (two per workgroup) for
+  // the rest -- most of a batch.  Otherwise a workgroup per pair (the hardware dispatcher is the work queue: a static
+  // share of ~24 pairs per persistent workgroup left the chip waiting for the unluckiest one, 0.755 vs 0.581 ms).
+  const int64_t grid = fused ? ceil_div(B, kDeferGroup) + ceil_div(B, kSealBlock / 64) : (B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
+  hipLaunchKernelGGL(seal_subgraph_kernel, dim3(static_cast<unsigned>(grid)), dim3(kSealBlock), 0, st, adj_rowptr, adj_col,
                      n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag,
-                     tag_present, hub_bits ? hub_index : nullptr, hub_bits, static_cast<int>(hub_words));
+                     tag_present, hidx, hub_bits, static_cast<int>(hub_words), fused ? 1 : 0);
   return check_launch("seal_subgraphs");
 }
 

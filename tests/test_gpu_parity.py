@@ -1370,6 +1370,35 @@ def test_seal_head_with_reference_weights(dev, sl, golden_dir):
     assert torch.equal(s3, score) and torch.equal(lab3, lab)
 
 
+@pytest.mark.parametrize("hop,max_nb", [(1, 100), (1, 12), (0, 100), (1, 34)])
+def test_seal_wave_per_pair_matches_workgroup_kernel(dev, sl, lpg_options, hop, max_nb):
+    """lpg_seal_subgraphs' two forms -- one 64-lane wave per small pair + a queue of the rest for the 128-thread
+    workgroups (default), and the workgroup kernel alone (option seal_pair_small = 0) -- on the same pairs: node lists,
+    sizes, DRNL tags, adjacency bits, cap flags and the tag presence table bit for bit.  fb-pages-food (self loops,
+    u == v, isolated targets) and the 236 K-node RMAT graph (hubs inside small subgraphs: rows filled by symmetry,
+    hub x hub entries from the hub bit matrix); cap thresholds on either side of the wave path's 32-vertex limit."""
+    import bench
+    from lpgnn_amd import seal
+    rng = np.random.default_rng(hop * 7 + max_nb)
+    pos = sl["positive"].astype(np.int64)
+    fb = seal.build_train_csr(pos, 620, test_ratio=0.1, device=dev)
+    fb_pairs = np.concatenate([pos[:600], rng.integers(0, 620, size=(1500, 2)), np.stack([np.arange(620)] * 2, 1)])
+    N, E = 235_868, 1_285_465
+    ei = bench.rmat_edges(N, E, 1, dev)
+    big = seal.build_train_csr(ei.t().contiguous(), N, test_ratio=0.0, device=dev)
+    big_pairs = np.concatenate([rng.integers(0, N, size=(20_000, 2)), _np(ei[:, :3000].t())])
+    n_wave = 0
+    for graph, pairs in ((fb, fb_pairs), (big, big_pairs)):
+        lpg_options(seal_pair_small=1)
+        a = seal.extract_subgraphs(pairs, graph, hop, max_neighbors=max_nb, cap_policy="device", seed=3)
+        lpg_options(seal_pair_small=0)
+        b = seal.extract_subgraphs(pairs, graph, hop, max_neighbors=max_nb, cap_policy="device", seed=3)
+        for name in ("n", "nodes", "tags", "adj_bits", "capped", "tag_present"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        n_wave += int(((a.n <= 32) & (a.capped == 0)).sum())
+    assert n_wave > 5000                                  # the wave path really took most of them
+
+
 def test_seal_capped_pairs_device_policy(dev, sl):
     """pairs that hit the reference's RNG-dependent 100-node truncation: the on-device policy must
     produce a valid outcome of that branch (u, v kept; the rest a subset of N(u) U N(v); size within
