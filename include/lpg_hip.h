@@ -48,7 +48,7 @@ int lpg_abi_version(void);
  * the environment at all.  Every value a release build accepts selects between variants that all return correct
  * results (the tests pin each to the oracle): "spmm_chunk", "spmm_mode" (0 / 1), "spmm_lds", "spmm_block",
  * "spmm_off32", "spmm_rows_max", "spmm_rows_ecap", "spmm_no_edge", "seal_conv_fp32", "gn_small",
- * "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant), "seal_pair_small",
+ * "seal_conv_variant", "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant), "seal_pair_small",
  * "spmm_phase_timing" (1: lpg_csr_spmm_* record events around their kernels, see lpg_csr_spmm_phase_ms).
  * `name` is a HOST string.  set: 0 / LPG_E_INVALID (unknown name, value out of range); get: the value, INT64_MIN
  * for an unknown name.  lpg_tuning_build() = 1 for a -DLPG_TUNING build (profiles/ sweeps only: seeds the table
@@ -364,6 +364,13 @@ int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_off, const 
                            const int32_t* tag_map, int64_t tag_map_len, int64_t T, const float* w1_tag,
                            const float* p_table, int64_t n_graph, int64_t B, float* h1, int64_t ldh,
                            int32_t* err_flag, void* stream);
+/* bf16 storage (configs[2]): the same two fp32 table gathers and add, the sum rounded ONCE to bf16 -- what
+ * bf16(X W_1) with fp32 accumulation gives when X = [onehot || emb] and W_1 hold bf16 values (p_table = the fp32
+ * product of the bf16-valued emb and W_1[T:]).  h1 rows 8-byte aligned. */
+int lpg_seal_h1_tables_bf16(const int32_t* nodes, const int64_t* node_off, const int32_t* tags,
+                            const int32_t* tag_map, int64_t tag_map_len, int64_t T, const float* w1_tag,
+                            const float* p_table, int64_t n_graph, int64_t B, uint16_t* h1, int64_t ldh,
+                            int32_t* err_flag, void* stream);
 
 /* Layers 1..4 of the reference's fixed SEAL architecture (graph weights [F,32], [32,32], [32,32], [32,1];
  * SEAL/model/gnn.py:32-42,46-63) for a whole batch as dense 32 x 32 block products on the fp32 matrix cores,
@@ -375,8 +382,11 @@ int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_off, const 
  * start in its 128-row window.  w2, w3 are [32,32] with the INPUT index major (TensorFlow's x @ W), w4 is [32].
  * Head fusion: with head_k1 [96,16] (conv1d_kernel_1 of the DGCNN head, SEAL/model/gnn.py:104-110, a per-vertex
  * linear on the concat) the kernel also writes head_a16 [total,16] = [Z_1|Z_2|Z_3] @ head_k1; cat may then be NULL
- * (the 96-wide concat is never written).  The aggregation runs on the bf16 matrix cores through an exact three-way
- * bf16 split of H (0/1/2 adjacency entries are exact in bf16); LPG_SEAL_CONV_FP32=1 keeps the fp32 MFMA form. */
+ * (the 96-wide concat is never written).  Every product runs on the bf16 matrix cores: the aggregation through an
+ * exact three-way bf16 split of H (0/1/2 adjacency entries are exact in bf16), the dense products H' = Z W and
+ * a16 += Z k1 through the six leading plane pairs of the two splits (what is dropped is <= 2^-24 |z||w| per term: one
+ * fp32 rounding).  Options: "seal_conv_variant" = 1 keeps the dense products on the fp32 matrix cores (the round-1
+ * kernel), "seal_conv_fp32" = 1 the first all-fp32-MFMA formulation. */
 /* The index of a batch of subgraphs in one launch: node_off [B + 1] = exclusive scan of the sizes n_nodes [B]
  * (the row offsets of the block-diagonal batch, SEAL/config/data.py:94-117 stacks per-graph arrays); tag_map
  * [n_tags] = rank of every PRESENT tag among the present ones, -1 for the others -- the global tag compaction of
@@ -399,6 +409,16 @@ int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* first, int64
                             const uint32_t* adj_bits, const float* h1, int64_t ldh, const float* w2,
                             const float* w3, const float* w4, float* cat, int64_t ldc, float* key,
                             const float* head_k1, float* head_a16, void* stream);
+/* The same stack in bf16 STORAGE (BASELINE configs[2]: "d = 128, bf16"): h1, the weights and cat are bf16, H and Z are
+ * rounded to bf16 (nearest even) where the layer-by-layer bf16 path stores them, accumulation is fp32, key and
+ * head_a16 stay fp32 (head_k1 is the head's fp32 kernel: its product with the bf16 Z is exact to fp32 rounding).
+ * One bf16 plane instead of three: 2 MFMAs per block product, 17 KB of LDS per workgroup instead of 51.
+ * h1 / cat rows 8-byte aligned (ldh, ldc multiples of 4). */
+int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* first, int64_t n_windows,
+                             const uint32_t* adj_bits, const uint16_t* h1, int64_t ldh,
+                             const uint16_t* w2, const uint16_t* w3, const uint16_t* w4, uint16_t* cat,
+                             int64_t ldc, float* key, const float* head_k1, float* head_a16,
+                             void* stream);
 
 /* The DGCNN head's last dense layer and its softmax in one launch (SEAL/model/gnn.py:127-137): pre_y [B, 2] =
  * h [B, H] @ w [H, 2] + bias [2] (w as TensorFlow stores it, input index major), score [B] = softmax(pre_y)[:, 1]. */

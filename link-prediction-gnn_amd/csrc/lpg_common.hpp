@@ -30,6 +30,7 @@ struct Options {
   int64_t spmm_rows_ecap = int64_t(1) << 21;
   int64_t spmm_no_edge = 0;      // 1: narrow features (d <= 16) stay on the main kernel
   int64_t seal_conv_fp32 = 0;    // 1: the fp32-MFMA formulation of the SEAL conv stack (no head fusion)
+  int64_t seal_conv_variant = 0; // 0: every product on the bf16 matrix cores (csrc/seal_conv2.hip); 1: the r01 kernel (fp32 MFMA dense products)
   int64_t gn_small = 1;          // 0: GraphNorm keeps the three-launch path for small n
   int64_t linear_percu_delta = 0;
   int64_t linear_wres = -1;      // -1 automatic; 0 off; 1 / 2 / 3 force that W-resident variant (also below n_min)
@@ -85,6 +86,11 @@ int linear_wres_f32(const float* x, int64_t ldx, const float* w, int w_is_km, co
                     int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st);
 int linear_wres_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, int w_is_km, const float* bias, int act,
                      uint16_t* y, int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st);
+
+// seal_conv2.hip: the SEAL conv stack with every product on the bf16 matrix cores (fp32-class plane arithmetic)
+int seal_conv2_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows, const uint32_t* adj_bits,
+                   const float* h1, int64_t ldh, const float* w2, const float* w3, const float* w4, float* cat, int64_t ldc,
+                   float* key, const float* head_k1, float* head_a16, hipStream_t st);
 
 __device__ __forceinline__ void flag_error(int32_t* err_flag, int32_t bit) {
   if (err_flag) atomicOr(err_flag, bit);

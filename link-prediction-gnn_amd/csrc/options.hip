@@ -31,6 +31,7 @@ const Entry kEntries[] = {
     {"spmm_rows_ecap", &Options::spmm_rows_ecap, 0, int64_t(1) << 40},
     {"spmm_no_edge", &Options::spmm_no_edge, 0, 1},
     {"seal_conv_fp32", &Options::seal_conv_fp32, 0, 1},
+    {"seal_conv_variant", &Options::seal_conv_variant, 0, 1},
     {"gn_small", &Options::gn_small, 0, 1},
     {"linear_percu_delta", &Options::linear_percu_delta, -8, 8},
     {"linear_wres", &Options::linear_wres, -1, 3},

@@ -895,13 +895,14 @@ __global__ __launch_bounds__(kBlock) void seal_features_kernel(const int32_t* __
 // gathers and an add per vertex instead of writing 544 B of X and reading it back through a GEMM
 // (features 0.46 ms + linear 0.22 ms -> 0.1 ms per 100 K candidates).  Same sum, different association.
 constexpr int kH1Block = 64;     // ONE wave per subgraph: 8 rows per step cover the typical subgraph (mean 15 vertices) in two
+template <typename TOUT>
 __global__ __launch_bounds__(kH1Block) void seal_h1_tables_kernel(const int32_t* __restrict__ nodes,
                                                                const int64_t* __restrict__ node_off,
                                                                const int32_t* __restrict__ tags,
                                                                const int32_t* __restrict__ tag_map, int64_t tag_map_len,
                                                                int64_t T, const float* __restrict__ w1_tag,
                                                                const float* __restrict__ p_table, int64_t n_graph,
-                                                               int64_t B, float* __restrict__ h1, int64_t ldh,
+                                                               int64_t B, TOUT* __restrict__ h1, int64_t ldh,
                                                                int32_t* err_flag) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c4 = (lane & 7) * 4, sub = lane >> 3;   // 8 lanes x float4 cover a 32-wide row; 8 rows per wave step
@@ -925,9 +926,16 @@ __global__ __launch_bounds__(kH1Block) void seal_h1_tables_kernel(const int32_t*
       if (!ok && i < n && c4 == 0) flag_error(err_flag, LPG_F_INDEX_RANGE);
       const float4 a = *reinterpret_cast<const float4*>(w1_tag + static_cast<int64_t>(ok ? tg : 0) * 32 + c4);
       const float4 q = *reinterpret_cast<const float4*>(p_table + static_cast<int64_t>(ok ? nd : 0) * 32 + c4);
-      if (i < n)
-        *reinterpret_cast<float4*>(h1 + (base + i) * ldh + c4) =
-            ok ? make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 sum = ok ? make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n) {
+        if constexpr (sizeof(TOUT) == 4) {
+          *reinterpret_cast<float4*>(h1 + (base + i) * ldh + c4) = sum;
+        } else {                                       // bf16 storage: ONE rounding of the fp32 sum (nearest even)
+          *reinterpret_cast<uint2*>(h1 + (base + i) * ldh + c4) =
+              make_uint2(f32_to_bf16(sum.x) | (static_cast<uint32_t>(f32_to_bf16(sum.y)) << 16),
+                         f32_to_bf16(sum.z) | (static_cast<uint32_t>(f32_to_bf16(sum.w)) << 16));
+        }
+      }
     }
   }
 }
@@ -1275,9 +1283,24 @@ LPG_EXPORT int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   LPG_REQUIRE(al16(w1_tag) && al16(p_table) && al16(h1), "seal_h1_tables: tables and output must be 16-byte aligned");
   const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));   // a workgroup per subgraph (see lpg_seal_subgraphs)
-  hipLaunchKernelGGL(seal_h1_tables_kernel, dim3(grid), dim3(kH1Block), 0, as_stream(stream), nodes, node_off, tags, tag_map,
+  hipLaunchKernelGGL(seal_h1_tables_kernel<float>, dim3(grid), dim3(kH1Block), 0, as_stream(stream), nodes, node_off, tags, tag_map,
                      tag_map_len, T, w1_tag, p_table, n_graph, B, h1, ldh, err_flag);
   return check_launch("seal_h1_tables");
+}
+
+LPG_EXPORT int lpg_seal_h1_tables_bf16(const int32_t* nodes, const int64_t* node_off, const int32_t* tags,
+                                       const int32_t* tag_map, int64_t tag_map_len, int64_t T, const float* w1_tag,
+                                       const float* p_table, int64_t n_graph, int64_t B, uint16_t* h1, int64_t ldh,
+                                       int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(B >= 0 && T >= 1 && n_graph >= 1 && ldh >= 32 && ldh % 4 == 0, "seal_h1_tables_bf16: bad sizes (ldh >= 32, a multiple of 4)");
+  if (B == 0) return LPG_OK;
+  LPG_REQUIRE(nodes && node_off && tags && w1_tag && p_table && h1, "seal_h1_tables_bf16: null pointer");
+  auto al = [](const void* p, int a) { return reinterpret_cast<uintptr_t>(p) % a == 0; };
+  LPG_REQUIRE(al(w1_tag, 16) && al(p_table, 16) && al(h1, 8), "seal_h1_tables_bf16: tables 16-byte, output 8-byte aligned");
+  const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
+  hipLaunchKernelGGL(seal_h1_tables_kernel<uint16_t>, dim3(grid), dim3(kH1Block), 0, as_stream(stream), nodes, node_off, tags,
+                     tag_map, tag_map_len, T, w1_tag, p_table, n_graph, B, h1, ldh, err_flag);
+  return check_launch("seal_h1_tables_bf16");
 }
 
 LPG_EXPORT int lpg_seal_sortpool_f32(const float* z, int64_t ldz, const float* key, const int64_t* node_off, int64_t B,

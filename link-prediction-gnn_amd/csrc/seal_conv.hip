@@ -529,6 +529,9 @@ LPG_EXPORT int lpg_seal_conv_stack_f32(const int64_t* node_off, const int32_t* f
   }
   LPG_REQUIRE((!cat || (al16(cat) && ldc % 4 == 0)) && (!head_a16 || al16(head_a16)),
               "seal_conv_stack: cat / head_a16 must be 16-byte aligned (ldc a multiple of 4)");
+  if (options().seal_conv_variant == 0 && al16(h1) && ldh % 4 == 0)      // default: csrc/seal_conv2.hip (coalesced H_1 rows)
+    return seal_conv2_f32(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16,
+                          as_stream(stream));
   hipLaunchKernelGGL(seal_conv_t_kernel, dim3(static_cast<unsigned>(n_windows)), dim3(kConvBlock), 0, as_stream(stream),
                      node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16);
   return check_launch("seal_conv_stack");

@@ -1,0 +1,434 @@
+// SEAL graph convolution, layers 1..4 (SEAL/model/gnn.py:46-63), second formulation of the dense-block stack: every
+// matrix product of the stack on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), in two numeric classes
+//
+//   NP = 3  fp32 storage, fp32-class arithmetic.  An fp32 value is three bf16 terms (hi | mid | lo: 8 + 8 + 8 mantissa
+//           bits, exact -- csrc/seal_conv.hip split3).  The aggregation (A + I) H has exact 0 / 1 / 2 entries on one side,
+//           so its three plane products are exact and summed in the MFMA's fp32 accumulator.  The two dense products
+//           of a layer, H' = Z W and a16 += Z k1, keep the six plane pairs whose weight is >= 2^-16 of the leading one
+//           (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid); the three dropped pairs are <= 2^-24 |z| |w| each, the
+//           size of one fp32 rounding of the same product.  12 MFMAs of 8 passes per 32 x 32 x 32 product instead of
+//           16 v_mfma_f32_32x32x2_f32 of 16 passes each (the r01 kernel, kept as option seal_conv_variant = 1).
+//   NP = 1  bf16 storage (BASELINE configs[2]: "d = 128, bf16"): H and Z are rounded to bf16 (nearest even) wherever
+//           the generic bf16 path stores them, weights are bf16, one plane everywhere: 2 MFMAs per aggregation block,
+//           2 per dense product; the planes take 17 KB of LDS instead of 51.
+//
+// Layout of the products is the transposed one of seal_conv_t_kernel (lane = vertex, registers = features; the A
+// operand of the aggregation is a fragment of H^T, the B operand 8 bits of the lane's own adjacency row through a byte
+// table): see that kernel's header.  What is new besides the plane products:
+//   * the H_1 planes are filled from COALESCED reads -- a lane takes two consecutive rows x four features (two 16-byte
+//     loads of 64-byte row segments: 16 cache lines per wave instruction) and writes row-pair dwords into the planes
+//     conflict-free; the r01 kernel walked one feature across rows (64 cache lines per instruction, 32 instructions
+//     per thread: the texture pipe, not the matrix pipe, bounded its set-up phase);
+//   * W_2, W_3 and the head's conv1d #1 slices are staged in LDS as ready-made bf16 A-operand fragments per plane.
+#include <stdlib.h>
+
+#include "lpg_common.hpp"
+
+namespace {
+using namespace lpg;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+
+constexpr int MAXN = LPG_SEAL_MAXN;   // 128
+constexpr int WORDS = MAXN / 32;
+constexpr int WIN = 128;              // a workgroup owns the subgraphs that start in a 128-row window
+constexpr int RMAX = WIN + MAXN;      // rows it can end up with (<= 255)
+constexpr int kConvBlock = 256;       // 4 waves, up to two 32-row tiles each
+constexpr int HS = 256 + 8;           // row stride of a transposed bf16 plane (528 B: 16-byte aligned; 132 dwords = 4 mod 16)
+
+__device__ __forceinline__ float tanh_fast_div(float v) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f); }
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(uint16_t v) { return bf16_to_f32(v); }
+
+// bf16 planes of a value: NP = 3 exact truncation split, NP = 1 round to nearest even
+template <int NP>
+__device__ __forceinline__ void planes_of(float v, uint32_t (&p)[NP]) {
+  if constexpr (NP == 1) {
+    p[0] = f32_to_bf16(v);
+  } else {
+    const uint32_t uh = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(uh);
+    const uint32_t um = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(um);
+    p[0] = uh >> 16; p[1] = um >> 16; p[2] = __float_as_uint(r2) >> 16;
+  }
+}
+
+// plane pairs (value plane, weight plane) of a dense product, smallest terms first
+template <int NP> struct Terms;
+template <> struct Terms<1> {
+  static constexpr int N = 1;
+  static constexpr int zp[1] = {0};
+  static constexpr int wp[1] = {0};
+};
+template <> struct Terms<3> {
+  static constexpr int N = 6;
+  static constexpr int zp[6] = {1, 2, 0, 1, 0, 0};
+  static constexpr int wp[6] = {1, 0, 2, 0, 1, 0};
+};
+// against a weight that always has three planes (the head's fp32 conv1d #1 kernel)
+template <int NP> struct KTerms;
+template <> struct KTerms<1> {
+  static constexpr int N = 3;
+  static constexpr int zp[3] = {0, 0, 0};
+  static constexpr int wp[3] = {2, 1, 0};
+};
+template <> struct KTerms<3> : Terms<3> {};
+
+struct RowCtxT {
+  int i, start;        // vertex index inside its subgraph (-100000: no row), the subgraph's first local row
+  float one;           // D^-1 of the row (0: no row)
+  uint32_t dadd;       // what "+ 1.0" is on the diagonal's bf16: 0x0080 when it already holds 1.0 (self loop), else 0x3F80
+  uint32_t b0, b1, b2, b3;
+  int j_lo, j_hi;      // column tiles the tile's subgraphs overlap
+};
+
+template <int NP, typename TIN, bool CAT>
+__global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
+    const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
+    const TIN* __restrict__ h1, int64_t ldh, const TIN* __restrict__ w2, const TIN* __restrict__ w3,
+    const TIN* __restrict__ w4, TIN* __restrict__ cat, int64_t ldc, float* __restrict__ key,
+    const float* __restrict__ k1, float* __restrict__ a16) {
+  __shared__ __attribute__((aligned(16))) uint16_t Hp[NP][32][HS];     // H^T as NP bf16 planes
+  __shared__ __attribute__((aligned(16))) uint4 lut[256];             // byte -> 8 x bf16 {0, 1}
+  __shared__ __attribute__((aligned(16))) uint4 Wb[2][NP][2][64];     // W_2, W_3: A fragments [layer][plane][k step][lane]
+  __shared__ __attribute__((aligned(16))) uint4 Kb[3][3][2][2][17];   // k1 slices (+ w4 in row 16 of layer 3): [layer][plane][k step][h][row]
+  __shared__ __attribute__((aligned(16))) uint4 W4b[NP][2][2];        // w4 alone (no head fusion): [plane][k step][h], row 0
+  __shared__ uint32_t rinfo[RMAX];
+  __shared__ int soff[WIN + 2];
+  __shared__ __attribute__((aligned(16))) float zt[CAT ? kConvBlock / 64 : 1][CAT ? 16 : 1][36];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bf = first[blockIdx.x], bl = first[blockIdx.x + 1];
+  if (bl <= bf) return;
+  const int nsub = bl - bf;
+  const int64_t r_lo = node_off[bf];
+  const int nrows = static_cast<int>(node_off[bl] - r_lo);
+  const int ntiles = (nrows + 31) >> 5;             // <= 8
+
+  // ---- H_1 planes: a wave-sized group of items covers 16 row pairs x 4 feature quads (half a 32-row tile, half the
+  // features): lane (i = l & 15, q = l >> 4) reads the 16-byte pieces [4 kq, 4 kq + 4) of rows 2 rp and 2 rp + 1 and
+  // writes 12 (or 4) row-pair dwords; dword index = feature * 132 + rp, so the 64 lanes of a write hit 64 banks.
+  for (int idx = tid; idx < ntiles * 128; idx += kConvBlock) {
+    const int g = idx >> 6, l = idx & 63;
+    const int rp = (g >> 1) * 16 + (l & 15), kq = (g & 1) * 4 + (l >> 4), row = 2 * rp;
+    float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};   // rows past the end are zero (0 x NaN is not)
+    if constexpr (sizeof(TIN) == 4) {
+      if (row < nrows) { const float4 q = *reinterpret_cast<const float4*>(h1 + (r_lo + row) * ldh + 4 * kq); v0[0] = q.x; v0[1] = q.y; v0[2] = q.z; v0[3] = q.w; }
+      if (row + 1 < nrows) { const float4 q = *reinterpret_cast<const float4*>(h1 + (r_lo + row + 1) * ldh + 4 * kq); v1[0] = q.x; v1[1] = q.y; v1[2] = q.z; v1[3] = q.w; }
+    } else {
+      if (row < nrows) { const uint2 q = *reinterpret_cast<const uint2*>(h1 + (r_lo + row) * ldh + 4 * kq); v0[0] = bf16_to_f32(q.x & 0xFFFFu); v0[1] = bf16_to_f32(q.x >> 16); v0[2] = bf16_to_f32(q.y & 0xFFFFu); v0[3] = bf16_to_f32(q.y >> 16); }
+      if (row + 1 < nrows) { const uint2 q = *reinterpret_cast<const uint2*>(h1 + (r_lo + row + 1) * ldh + 4 * kq); v1[0] = bf16_to_f32(q.x & 0xFFFFu); v1[1] = bf16_to_f32(q.x >> 16); v1[2] = bf16_to_f32(q.y & 0xFFFFu); v1[3] = bf16_to_f32(q.y >> 16); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t a[NP], b[NP];
+      planes_of<NP>(v0[j], a);
+      planes_of<NP>(v1[j], b);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kq + j][row]) = a[p] | (b[p] << 16);
+    }
+  }
+  {                                                 // byte -> 8 bf16 (bit j set -> 1.0 = 0x3F80 in element j)
+    uint32_t d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      d[q] = (((tid >> (2 * q)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * q + 1)) & 1) ? 0x3F800000u : 0u);
+    lut[tid] = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+  // W_l[f][o] -> the A fragment of lane (o = ln & 31, hh = ln >> 5) for k step s2: f = acc_row(8 s2 + j, hh), j = 0..7
+  {
+    const int l = tid >> 7, s2 = (tid >> 6) & 1, ln = tid & 63;       // 2 x 2 x 64 = 256 fragments: one per thread
+    const TIN* w = l == 0 ? w2 : w3;
+    uint32_t pk[NP][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      uint32_t a[NP], b[NP];
+      planes_of<NP>(to_f32(w[acc_row(8 * s2 + 2 * jj, ln >> 5) * 32 + (ln & 31)]), a);
+      planes_of<NP>(to_f32(w[acc_row(8 * s2 + 2 * jj + 1, ln >> 5) * 32 + (ln & 31)]), b);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) pk[p][jj] = a[p] | (b[p] << 16);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) Wb[l][p][s2][ln] = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
+  }
+  if (k1) {
+    // k1[32 l + f][c] -> row c of the A operand (rows 0..15); row 16 of layer 3 = w4 (32 -> 1 rides along)
+    for (int idx = tid; idx < 3 * 2 * 2 * 17; idx += kConvBlock) {
+      const int row = idx % 17, hh = (idx / 17) & 1, s2 = (idx / 34) & 1, l = idx / 68;
+      uint32_t pk[3][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float va = 0.f, vb = 0.f;
+        const int fa = acc_row(8 * s2 + 2 * jj, hh), fb = acc_row(8 * s2 + 2 * jj + 1, hh);
+        if (row < 16) { va = k1[(l * 32 + fa) * 16 + row]; vb = k1[(l * 32 + fb) * 16 + row]; }
+        else if (l == 2) { va = to_f32(w4[fa]); vb = to_f32(w4[fb]); }
+        uint32_t a[3], b[3];
+        planes_of<3>(va, a);
+        planes_of<3>(vb, b);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pk[p][jj] = a[p] | (b[p] << 16);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) Kb[l][p][s2][hh][row] = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
+    }
+  } else if (tid < 4) {
+    const int s2 = tid >> 1, hh = tid & 1;
+    uint32_t pk[NP][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      uint32_t a[NP], b[NP];
+      planes_of<NP>(to_f32(w4[acc_row(8 * s2 + 2 * jj, hh)]), a);
+      planes_of<NP>(to_f32(w4[acc_row(8 * s2 + 2 * jj + 1, hh)]), b);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) pk[p][jj] = a[p] | (b[p] << 16);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) W4b[p][s2][hh] = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
+  }
+  // ---- per-subgraph offsets, per-row (subgraph, vertex)
+  for (int q = tid; q <= nsub; q += kConvBlock) soff[q] = static_cast<int>(node_off[bf + q] - r_lo);
+  __syncthreads();
+  for (int q = tid; q < nsub; q += kConvBlock)
+    for (int lr = soff[q]; lr < soff[q + 1]; ++lr) rinfo[lr] = (static_cast<uint32_t>(q) << 8) | static_cast<uint32_t>(lr - soff[q]);
+  __syncthreads();
+
+  auto row_ctx = [&](int I) {
+    RowCtxT c{-100000, 0, 0.f, 0x3F80u, 0u, 0u, 0u, 0u, 0, -1};
+    if (I >= ntiles) return c;
+    const int lr0 = 32 * I, lr1 = min(32 * I + 31, nrows - 1);
+    c.j_lo = soff[rinfo[lr0] >> 8] >> 5;
+    c.j_hi = (soff[(rinfo[lr1] >> 8) + 1] - 1) >> 5;
+    const int lr = 32 * I + r;
+    if (lr < nrows) {
+      const uint32_t ri = rinfo[lr];
+      const int q = static_cast<int>(ri >> 8);
+      c.i = static_cast<int>(ri & 255u);
+      c.start = soff[q];
+      const uint4 q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + q) * MAXN + c.i) * WORDS);
+      c.b0 = q4.x; c.b1 = q4.y; c.b2 = q4.z; c.b3 = q4.w;
+      const int pc = __popc(c.b0) + __popc(c.b1) + __popc(c.b2) + __popc(c.b3);
+      c.one = static_cast<float>(1.0 / static_cast<double>(pc + 1));             // D^-1 = 1 / rowsum(A + I)
+      const uint32_t wi = c.i < 32 ? c.b0 : (c.i < 64 ? c.b1 : (c.i < 96 ? c.b2 : c.b3));
+      c.dadd = ((wi >> (c.i & 31)) & 1u) ? 0x0080u : 0x3F80u;
+    }
+    return c;
+  };
+  const RowCtxT ctx0 = row_ctx(wave), ctx1 = row_ctx(wave + kConvBlock / 64);
+
+  // Z^T of a row tile: tanh(D^-1 sum_J H_J^T (A + I)_{IJ}^T); lane = vertex, register i = feature acc_row(i, h)
+  auto aggregate = [&](const RowCtxT& cx) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int J = cx.j_lo; J <= cx.j_hi; ++J) {
+      const int p0 = 32 * J - cx.start;
+      const int w = p0 >> 5, sh = p0 & 31;           // arithmetic shift: p0 may be negative
+      auto word = [&](int k) { return k == 0 ? cx.b0 : (k == 1 ? cx.b1 : (k == 2 ? cx.b2 : (k == 3 ? cx.b3 : 0u))); };
+      const uint32_t lo = word(w), hi = word(w + 1);
+      const uint32_t win = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+      const int cd = cx.i - p0;                      // the diagonal's column in this tile (out of range: none)
+      bf16x8 av[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 t = lut[(win >> (16 * s2 + 8 * h)) & 0xFFu];
+        const int dj = cd - (16 * s2 + 8 * h);
+        const uint32_t add = (dj >= 0 && dj < 8) ? (cx.dadd << (16 * (dj & 1))) : 0u;
+        const int sel = dj >> 1;
+        t.x += sel == 0 ? add : 0u;
+        t.y += sel == 1 ? add : 0u;
+        t.z += sel == 2 ? add : 0u;
+        t.w += sel == 3 ? add : 0u;
+        av[s2] = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int p = NP - 1; p >= 0; --p)              // smallest terms first
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 hv = *reinterpret_cast<const bf16x8*>(&Hp[p][r][32 * J + 16 * s2 + 8 * h]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hv, av[s2], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = tanh_fast_div(acc[i] * cx.one);
+    return acc;
+  };
+
+  f32x16 aa0, aa1;                                   // a16^T tiles (head fusion)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) aa0[i] = aa1[i] = 0.f;
+#pragma unroll 1
+  for (int layer = 1; layer <= 4; ++layer) {
+    f32x16 hn0, hn1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int I = wave + t * (kConvBlock / 64);
+      if (I >= ntiles) continue;                     // wave-uniform
+      const f32x16 z = aggregate(t == 0 ? ctx0 : ctx1);
+      const int lr = 32 * I + r;
+      if (layer == 4) {
+        if (h == 0 && lr < nrows) key[r_lo + lr] = z[0];            // feature 0
+        continue;
+      }
+      if constexpr (CAT) {
+        if (cat) {
+          // half a tile at a time through a wave-private LDS slice: the rows leave as whole lines
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            if ((r >> 4) == half) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g)                // features 8 g + 4 h + {0..3}
+                *reinterpret_cast<float4*>(&zt[wave][r & 15][8 * g + 4 * h]) = make_float4(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the slice is wave-private
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int row = (lane >> 3) + 8 * k, quad = lane & 7;
+              const float4 v = *reinterpret_cast<const float4*>(&zt[wave][row][4 * quad]);
+              const int lrr = 32 * I + 16 * half + row;
+              if (lrr < nrows) {
+                TIN* dst = cat + (r_lo + lrr) * ldc + (layer - 1) * 32 + 4 * quad;
+                if constexpr (sizeof(TIN) == 4) {
+                  *reinterpret_cast<float4*>(dst) = v;
+                } else {
+                  *reinterpret_cast<uint2*>(dst) = make_uint2(f32_to_bf16(v.x) | (static_cast<uint32_t>(f32_to_bf16(v.y)) << 16),
+                                                              f32_to_bf16(v.z) | (static_cast<uint32_t>(f32_to_bf16(v.w)) << 16));
+                }
+              }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+      // Z^T as bf16 B fragments: k step s2 takes the lane's registers 8 s2 .. 8 s2 + 7 (features acc_row(8 s2 + j, h))
+      bf16x8 zb[NP][2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint32_t pk[NP][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          uint32_t a[NP], b[NP];
+          planes_of<NP>(z[8 * s2 + 2 * jj], a);
+          planes_of<NP>(z[8 * s2 + 2 * jj + 1], b);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) pk[p][jj] = a[p] | (b[p] << 16);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          uint4 q = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
+          zb[p][s2] = *reinterpret_cast<bf16x8*>(&q);
+        }
+      }
+      // H'^T = W^T Z^T
+      f32x16 hn;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hn[i] = 0.f;
+      const bool merged = k1 && layer == 3;          // 32 -> 1 (w4) rides in row 16 of the conv1d #1 product
+      if (layer < 3) {
+#pragma unroll
+        for (int q = 0; q < Terms<NP>::N; ++q)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const uint4 wv = Wb[layer - 1][Terms<NP>::wp[q]][s2][lane];
+            hn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wv), zb[Terms<NP>::zp[q]][s2], hn, 0, 0, 0);
+          }
+      } else if (!merged) {                          // 32 -> 1: only output row o = 0 is non-zero
+#pragma unroll
+        for (int q = 0; q < Terms<NP>::N; ++q)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 wv = W4b[Terms<NP>::wp[q]][s2][h];
+            if (r != 0) wv = make_uint4(0u, 0u, 0u, 0u);
+            hn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wv), zb[Terms<NP>::zp[q]][s2], hn, 0, 0, 0);
+          }
+      }
+      if (t == 0) hn0 = hn; else hn1 = hn;
+      if (k1) {                                      // wave-uniform
+        f32x16 aa = t == 0 ? aa0 : aa1;
+#pragma unroll
+        for (int q = 0; q < KTerms<NP>::N; ++q)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 kv = Kb[layer - 1][KTerms<NP>::wp[q]][s2][h][r <= 16 ? r : 16];
+            if (r > 16 || (r == 16 && !merged)) kv = make_uint4(0u, 0u, 0u, 0u);
+            aa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&kv), zb[KTerms<NP>::zp[q]][s2], aa, 0, 0, 0);
+          }
+        if (t == 0) aa0 = aa; else aa1 = aa;
+        if (layer == 3 && lr < nrows) {              // outputs c = acc_row(i, h) < 16  <=>  i < 8
+          *reinterpret_cast<float4*>(a16 + (r_lo + lr) * 16 + 4 * h) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+          *reinterpret_cast<float4*>(a16 + (r_lo + lr) * 16 + 8 + 4 * h) = make_float4(aa[4], aa[5], aa[6], aa[7]);
+        }
+      }
+    }
+    if (layer == 4) break;
+    __syncthreads();                                 // every aggregation of this layer has read H
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int I = wave + t * (kConvBlock / 64);
+      if (I >= ntiles) continue;
+      if (k1 && layer == 3) {
+        // layer 4 reads feature 0 only (the sort key): it sits in row 16 of the merged product
+        if (h == 0) {
+          uint32_t pl[NP];
+          planes_of<NP>(t == 0 ? aa0[8] : aa1[8], pl);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) Hp[p][0][32 * I + r] = static_cast<uint16_t>(pl[p]);
+        }
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                 // lane = vertex 32 I + r, register i = feature acc_row(i, h)
+        uint32_t pl[NP];
+        planes_of<NP>(t == 0 ? hn0[i] : hn1[i], pl);
+        const int f = acc_row(i, h);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) Hp[p][f][32 * I + r] = static_cast<uint16_t>(pl[p]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NP, typename TIN>
+int launch_conv2(const int64_t* node_off, const int32_t* first, int64_t n_windows, const uint32_t* adj_bits, const TIN* h1,
+                 int64_t ldh, const TIN* w2, const TIN* w3, const TIN* w4, TIN* cat, int64_t ldc, float* key,
+                 const float* head_k1, float* head_a16, hipStream_t st) {
+  const dim3 grid(static_cast<unsigned>(n_windows)), blk(kConvBlock);
+  if (cat)
+    hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, true>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat,
+                       ldc, key, head_k1, head_a16);
+  else
+    hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, false>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4,
+                       cat, ldc, key, head_k1, head_a16);
+  return check_launch("seal_conv_stack");
+}
+}  // namespace
+
+namespace lpg {
+int seal_conv2_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows, const uint32_t* adj_bits,
+                   const float* h1, int64_t ldh, const float* w2, const float* w3, const float* w4, float* cat, int64_t ldc,
+                   float* key, const float* head_k1, float* head_a16, hipStream_t st) {
+  return launch_conv2<3, float>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16, st);
+}
+}  // namespace lpg
+
+LPG_EXPORT int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* first, int64_t n_windows,
+                                        const uint32_t* adj_bits, const uint16_t* h1, int64_t ldh, const uint16_t* w2,
+                                        const uint16_t* w3, const uint16_t* w4, uint16_t* cat, int64_t ldc, float* key,
+                                        const float* head_k1, float* head_a16, void* stream) {
+  LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && ldh >= 32 && ldh % 4 == 0 && (!cat || (ldc >= 96 && ldc % 4 == 0)),
+              "seal_conv_stack_bf16: bad sizes (ldh, ldc multiples of 4)");
+  if (n_windows == 0) return LPG_OK;
+  LPG_REQUIRE(node_off && first && adj_bits && h1 && w2 && w3 && w4 && key, "seal_conv_stack_bf16: null pointer");
+  LPG_REQUIRE((cat || head_k1) && (!head_k1 == !head_a16), "seal_conv_stack_bf16: needs cat, or head_k1 together with head_a16");
+  auto al = [](const void* p, int a) { return reinterpret_cast<uintptr_t>(p) % a == 0; };
+  LPG_REQUIRE(al(h1, 8) && (!cat || al(cat, 8)) && (!head_a16 || al(head_a16, 16)),
+              "seal_conv_stack_bf16: h1 / cat must be 8-byte aligned, head_a16 16-byte aligned");
+  return launch_conv2<1, uint16_t>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16,
+                                   as_stream(stream));
+}

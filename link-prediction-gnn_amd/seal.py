@@ -439,38 +439,45 @@ _p_table_cache = {}
 def first_layer_h1(batch, tag_map, tags_size, emb, w1, check=True):
     """H_1 = X W_1 for X = [onehot(tag) || emb[node]] WITHOUT building X (SEAL/config/data.py:129-140 +
     SEAL/model/gnn.py:46): a one-hot row times W_1 is a row of W_1, and emb[node] @ W_1[T:] is row `node` of
-    P = emb @ W_1[T:] (one small matmul), so H_1[g] = W_1[tag_g] + P[node_g].  fp32, W_1 [T + dim, 32]."""
+    P = emb @ W_1[T:] (one small matmul), so H_1[g] = W_1[tag_g] + P[node_g].  W_1 [T + dim, 32].
+    bf16 emb / W_1 (bf16 storage, configs[2]): the tables are the fp32 products of the bf16 values and H_1 is rounded
+    once to bf16 -- bf16(X W_1) with fp32 accumulation."""
     lib = _lib.load()
     T = int(tags_size)
-    w1 = _ops._c(w1, torch.float32)
+    bf16 = emb.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
+    w1_in, emb_in = w1, emb
+    w1 = _ops._c(w1, torch.float32)          # (cached below per (emb, W_1) version: the conversions run once)
     emb = _ops._c(emb, torch.float32)
     if w1.shape[1] != 32 or w1.shape[0] != T + emb.shape[1]:
         raise ValueError(f"first_layer_h1: W_1 must be [{T + emb.shape[1]}, 32], got {tuple(w1.shape)}")
     w1_tag = w1[:T].contiguous()
     # P depends on the parameters only (embedding table, W_1): computed once per (emb, W_1, T) version
-    ck = (emb.data_ptr(), emb._version, w1.data_ptr(), w1._version, T, tuple(emb.shape))
+    ck = (emb_in.data_ptr(), emb_in._version, w1_in.data_ptr(), w1_in._version, T, tuple(emb_in.shape), bf16)
     hit = _p_table_cache.get(ck)
     if hit is None:
         if len(_p_table_cache) > 4:
             _p_table_cache.clear()
-        hit = _p_table_cache[ck] = (_ops.linear(emb, w1[T:], w_is_km=True), emb, w1)     # [n_graph, 32]; keeps the keys alive
-    p_table = hit[0]
+        # [n_graph, 32] fp32 (for bf16 inputs: the fp32 product of the bf16 values); keeps the key tensors alive
+        hit = _p_table_cache[ck] = (_ops.linear(emb, w1[T:], w_is_km=True), w1_tag, emb_in, w1_in)
+    p_table, w1_tag = hit[0], hit[1]
     off = batch.node_off()
     total = batch.total()
-    h1 = torch.empty((total, 32), dtype=torch.float32, device=emb.device)
+    h1 = torch.empty((total, 32), dtype=torch.bfloat16 if bf16 else torch.float32, device=emb.device)
     P = _ops._ptr
-    _lib.check(lib.lpg_seal_h1_tables_f32(P(batch.nodes), P(off), P(batch.tags), P(tag_map), tag_map.numel(), T,
-                                          P(w1_tag), P(p_table), emb.shape[0], batch.B, P(h1), h1.stride(0),
-                                          P(_ops.err_flag(emb.device)), _ops._stream()), "seal_h1_tables")
+    fn = lib.lpg_seal_h1_tables_bf16 if bf16 else lib.lpg_seal_h1_tables_f32
+    _lib.check(fn(P(batch.nodes), P(off), P(batch.tags), P(tag_map), tag_map.numel(), T, P(w1_tag), P(p_table),
+                  emb.shape[0], batch.B, P(h1), h1.stride(0), P(_ops.err_flag(emb.device)), _ops._stream()), "seal_h1_tables")
     if check:                                         # check=False: the flag is read by the next checking op (head())
         _ops.maybe_check(emb.device, "seal first-layer index")
     return h1
 
 
 def _dense_ok(weights, dtype=torch.float32):
-    """the reference's fp32 architecture: graph weights [F,32], [32,32], [32,32], [32,1] (SEAL/model/gnn.py:32-42)"""
-    return (dtype == torch.float32 and len(weights) == 4 and [tuple(w.shape)[1] for w in weights] == [32, 32, 32, 1]
-            and [tuple(w.shape)[0] for w in weights[1:]] == [32, 32, 32] and all(w.dtype == torch.float32 for w in weights)
+    """the reference's architecture: graph weights [F,32], [32,32], [32,32], [32,1] (SEAL/model/gnn.py:32-42), all fp32
+    or all bf16 (bf16 storage: configs[2])"""
+    return (dtype in (torch.float32, torch.bfloat16) and len(weights) == 4
+            and [tuple(w.shape)[1] for w in weights] == [32, 32, 32, 1]
+            and [tuple(w.shape)[0] for w in weights[1:]] == [32, 32, 32] and all(w.dtype == dtype for w in weights)
             and DENSE_STACK)
 
 
@@ -484,10 +491,12 @@ def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None, head_k1=None):
     (lpg_seal_conv_stack_f32; g / d_inv may then be None, and with h1 = first_layer_h1(...) so may x);
     otherwise the generic path:
     4 x (linear + block-diagonal CSR SpMM with the fused tanh epilogue)."""
-    if batch is not None and _dense_ok(weights, torch.float32 if x is None else x.dtype):
+    dt = (h1.dtype if h1 is not None else weights[0].dtype) if x is None else x.dtype
+    if batch is not None and _dense_ok(weights, dt):
         lib = _lib.load()
+        bf16 = dt == torch.bfloat16
         if h1 is None:
-            h1 = _ops.linear(x, weights[0], w_is_km=True)           # the one big matmul: X W_1
+            h1 = _ops.linear(x, weights[0], w_is_km=True)           # the one big matmul: X W_1 (bf16 storage: bf16 MFMA)
         total = h1.shape[0]                                          # (h1 given: first_layer_h1, X never built)
         off = batch.node_off()
         win = CONV_WINDOW                                            # rows per workgroup window (<= 128)
@@ -499,17 +508,19 @@ def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None, head_k1=None):
             _lib.check(lib.lpg_seal_conv_windows(_ops._ptr(off), batch.B, n_win, win, _ops._ptr(first), _ops._stream()),
                        "seal_conv_windows")
         fuse = head_k1 is not None
-        cat = None if fuse else torch.empty((total, 96), dtype=torch.float32, device=h1.device)
+        cat = None if fuse else torch.empty((total, 96), dtype=dt, device=h1.device)
         a16 = torch.empty((total, 16), dtype=torch.float32, device=h1.device) if fuse else None
         k1 = _ops._c(head_k1, torch.float32) if fuse else None
         if fuse and tuple(k1.shape) != (96, 16):
             raise ValueError("graph_conv_stack: head_k1 must be [96, 16]")
         key = torch.empty(total, dtype=torch.float32, device=h1.device)
-        w2, w3, w4 = (_ops._c(w, torch.float32) for w in weights[1:])
+        w2, w3, w4 = (_ops._c(w, dt) for w in weights[1:])
         P = _ops._ptr
-        _lib.check(lib.lpg_seal_conv_stack_f32(P(off), P(first), n_win, P(batch.adj_bits), P(h1), h1.stride(0), P(w2),
-                                               P(w3), P(w4), P(cat), 96, P(key), P(k1), P(a16), _ops._stream()),
-                   "seal_conv_stack")
+        fn = lib.lpg_seal_conv_stack_bf16 if bf16 else lib.lpg_seal_conv_stack_f32
+        _lib.check(fn(P(off), P(first), n_win, P(batch.adj_bits), P(h1), h1.stride(0), P(w2), P(w3), P(w4), P(cat), 96,
+                      P(key), P(k1), P(a16), _ops._stream()), "seal_conv_stack")
+        if bf16 and not fuse:
+            key = key.to(torch.bfloat16)                             # the layer-by-layer bf16 path returns Z_4 as stored
         return (a16 if fuse else cat), key
     if head_k1 is not None:
         raise ValueError("graph_conv_stack: head_k1 is fused only on the dense path (batch=, fp32 widths 32/32/32/1)")
@@ -608,7 +619,7 @@ def score_links(positive, negative, nodes_size, emb, weights, head_weights, test
     """the SEAL scoring forward end to end for a candidate set: structure (a10-a12), graph
     convolutions (a9) and the head.  Returns (scores [B], labels [B,1], batch)."""
     batch, labels, T, tag_map, _ = link2subgraph(positive, negative, nodes_size, test_ratio, hop, device=device)
-    if _dense_ok(weights) and emb is not None:          # X is never built: H_1 from two row gathers, then the dense stack
+    if emb is not None and _dense_ok(weights, weights[0].dtype) and emb.dtype == weights[0].dtype:   # X is never built: H_1 from two row gathers, then the dense stack
         k1 = head_weights["conv1d_kernel_1"]
         k1 = k1.reshape(-1, k1.shape[-1])
         fuse = tuple(k1.shape) == (96, 16) and _lib.get_option("seal_conv_fp32") == 0

@@ -1638,7 +1638,7 @@ def test_seal_graph_conv_bf16_storage(dev, sl, golden_dir):
     # X stored directly in bf16 by the features kernel == the fp32 X rounded once (round to nearest even)
     g16, dinv16, x16 = seal.gnn_inputs(batch, tag_map, T, emb, dtype=torch.bfloat16)
     assert x16.dtype == torch.bfloat16 and x16.stride(0) % 8 == 0 and torch.equal(x16, x.bfloat16())
-    for b in (None, batch):                                                    # generic block-CSR path / with the batch given
+    for b in (None, batch):                                  # layer by layer over the block CSR / the dense-block bf16 kernel
         z16, k16 = seal.graph_conv_stack(g16, dinv16, x16, w16, batch=b)
         assert z16.dtype == torch.bfloat16
         _check_seal_stack_bf16(batch, tag_map, T, emb.bfloat16(), w16, x16, z16, k16, list(range(0, 4202, 61)))
@@ -1859,11 +1859,24 @@ def test_config2_collab_seal_bf16_d128(dev):
     assert x16.dtype == torch.bfloat16 and x16.shape == (batch.total(), T + D)
     w16 = [(torch.randn(a, b, generator=gen, device=dev) * s).bfloat16()
            for a, b, s in ((T + D, 32, 0.15), (32, 32, 0.4), (32, 32, 0.4), (32, 1, 0.5))]
-    z16, k16 = seal.graph_conv_stack(g, d_inv, x16, w16, batch=batch)
-    assert z16.dtype == torch.bfloat16 and z16.shape == (batch.total(), 96) and k16.shape == (batch.total(),)
     n = _np(batch.n)
     picks = list(range(0, B, 41)) + [int(np.argmax(n)), int(np.argmin(n)), 0, 1, 31, 32]
-    worst = _check_seal_stack_bf16(batch, tag_map, T, emb16, w16, x16, z16, k16, picks)
+    worst = 0.0
+    # three routes through the product, all bf16 storage: layer by layer over the block CSR (4 x (bf16 linear + bf16
+    # SpMM)); bf16 linear for layer 1 + the dense-block bf16 kernel; H_1 from the two tables (X never built) + that kernel
+    h1 = seal.first_layer_h1(batch, tag_map, T, emb16, w16[0])
+    assert h1.dtype == torch.bfloat16 and h1.shape == (batch.total(), 32)
+    for route, (z16, k16) in (("layer by layer", seal.graph_conv_stack(g, d_inv, x16, w16)),
+                              ("dense blocks", seal.graph_conv_stack(None, None, x16, w16, batch=batch)),
+                              ("tables + dense blocks", seal.graph_conv_stack(None, None, None, w16, batch=batch, h1=h1))):
+        assert z16.dtype == torch.bfloat16 and z16.shape == (batch.total(), 96) and k16.shape == (batch.total(),), route
+        worst = max(worst, _check_seal_stack_bf16(batch, tag_map, T, emb16, w16, x16, z16, k16, picks))
+    # conv1d #1 of the head fused into the stack: a16 = [Z1|Z2|Z3] k1 from the bf16-rounded Z and the fp32 kernel
+    k1 = torch.randn(96, 16, generator=gen, device=dev) * 0.2
+    a16, kf = seal.graph_conv_stack(None, None, None, w16, batch=batch, h1=h1, head_k1=k1)
+    assert a16.dtype == torch.float32 and kf.dtype == torch.float32 and torch.equal(kf.to(torch.bfloat16), k16)
+    want, mag = z16.double() @ k1.double(), z16.double().abs() @ k1.double().abs()
+    assert torch.all((a16.double() - want).abs() <= TOL * mag + 1e-30)
     # head (fp32 arithmetic on the bf16 activations), random-init weights of the reference's DGCNN shapes (k = 18)
     hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, generator=gen, device=dev) * 0.1,
           "conv1d_kernel_2": torch.randn(5, 16, 32, generator=gen, device=dev) * 0.1,
