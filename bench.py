@@ -243,36 +243,43 @@ def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5
     # globally), so it is fitted once over all pairs, outside the timed region, identically on every rank
     tag_map, T = seal.compact_tag_map(seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0))
     torch.manual_seed(0)
-    gw = [torch.randn(a, b, device=device) * 0.1 for a, b in ((T + D, 32), (32, 32), (32, 32), (32, 1))]
+    gw32 = [torch.randn(a, b, device=device) * 0.1 for a, b in ((T + D, 32), (32, 32), (32, 32), (32, 1))]
     hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, device=device) * 0.1,
           "conv1d_kernel_2": torch.randn(5, 16, 32, device=device) * 0.1,
           "weight_1": torch.randn((k - 4) * 32, 128, device=device) * 0.1, "bias_1": torch.zeros(128, device=device),
           "weight_2": torch.randn(128, 2, device=device), "bias_2": torch.zeros(2, device=device)}
     k1 = hw["conv1d_kernel_1"].reshape(-1, 16)                                        # fused into the conv stack
+    lo_hi = ldist.ShardedLinkScorer(lambda p: p, world=world, rank=rank).my_slice(B)
+    timings = {}
+    # configs[2] names bf16 storage (features, weights, activations in bf16, fp32 accumulation); fp32 -- the reference's
+    # own arithmetic width -- is timed next to it
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        gw, e = [w.to(dt) for w in gw32], emb.to(dt)
 
-    def score_fn(p):
-        batch = seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=0)
-        h1 = seal.first_layer_h1(batch, tag_map, T, emb, gw[0], check=False)       # X W_1 from two row gathers, X never built
-        a16, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
-        return seal.head(None, key, batch.node_off(), hw, a_all=a16)[1]
+        def score_fn(p):
+            batch = seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=0)
+            h1 = seal.first_layer_h1(batch, tag_map, T, e, gw[0], check=False)       # X W_1 from two row gathers, X never built
+            a16, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
+            return seal.head(None, key, batch.node_off(), hw, a_all=a16)[1]
 
-    # No collective in here: a rank that fails must not leave the others hanging at a barrier and take the
-    # headline line down with it.  Scores stay sharded (gather=False; the all_gather is 4 B per scored edge);
-    # main() combines the per-rank times through the rendezvous store with a timeout.
-    scorer = ldist.ShardedLinkScorer(score_fn, world=world, rank=rank)
-    s = scorer(pairs, gather=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
+        # No collective in here: a rank that fails must not leave the others hanging at a barrier and take the
+        # headline line down with it.  Scores stay sharded (gather=False; the all_gather is 4 B per scored edge);
+        # main() combines the per-rank times through the rendezvous store with a timeout.
+        scorer = ldist.ShardedLinkScorer(score_fn, world=world, rank=rank)
         s = scorer(pairs, gather=False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
-    lo, hi = scorer.my_slice(B)
-    assert s.shape[0] == hi - lo
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            s = scorer(pairs, gather=False)
+        torch.cuda.synchronize()
+        timings[name] = (time.perf_counter() - t0) / iters
+        assert s.shape[0] == lo_hi[1] - lo_hi[0]
+    dt = timings["bf16"]
     return {"workload": f"synthetic collab-shaped SEAL scoring forward: |V|={N}, {E} undirected edges, {pairs_per_gpu} candidate "
-                        f"pairs per GPU x {world}, hop 1, d={D} fp32, pairs sharded across ranks (no data-path collective; "
-                        "value = all pairs / slowest rank's time)",
-            "scored_edges": B, "ms_per_forward": dt * 1e3, "scored_edges_per_s": B / dt}
+                        f"pairs per GPU x {world}, hop 1, d={D} bf16 storage (configs[2]), pairs sharded across ranks (no "
+                        "data-path collective; value = all pairs / slowest rank's time)",
+            "scored_edges": B, "ms_per_forward": dt * 1e3, "scored_edges_per_s": B / dt, "dtype": "bf16",
+            "fp32": {"ms_per_forward": timings["fp32"] * 1e3, "scored_edges_per_s": B / timings["fp32"]}}
 
 
 def combine_over_ranks(result, world, rank, timeout_s=180):
@@ -298,6 +305,9 @@ def combine_over_ranks(result, world, rank, timeout_s=180):
     ms = max(r["ms_per_forward"] for r in allr)
     out = dict(result)
     out["ms_per_forward"], out["scored_edges_per_s"] = ms, result["scored_edges"] / (ms * 1e-3)
+    if all("fp32" in r for r in allr):
+        ms32 = max(r["fp32"]["ms_per_forward"] for r in allr)
+        out["fp32"] = {"ms_per_forward": ms32, "scored_edges_per_s": result["scored_edges"] / (ms32 * 1e-3)}
     return out
 
 
@@ -627,6 +637,7 @@ def main():
                                "algorithmic_bytes_per_step": alg, "avg_launch_ms": kern_ms}
         # BASELINE.json's metric counts SCORED edges: the model-level forwards' figures, next to the kernel-level headline
         sc = {"seal_collab_100k": (out.get("seal_sharded") or {}).get("scored_edges_per_s"),
+              "seal_collab_100k_fp32": ((out.get("seal_sharded") or {}).get("fp32") or {}).get("scored_edges_per_s"),
               "seal_fb": (out.get("seal") or {}).get("scored_edges_per_s"),
               "twowl_fb": (out.get("twowl") or {}).get("scored_edges_per_s"),
               "twowl_fb_eager": (out.get("twowl") or {}).get("scored_edges_per_s_eager")}

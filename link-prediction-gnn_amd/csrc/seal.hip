@@ -894,7 +894,8 @@ __global__ __launch_bounds__(kBlock) void seal_features_kernel(const int32_t* __
 // P = emb W_1[T:] (one small matmul per (emb, W_1), |V| x 32).  So  H_1[g] = W_1[tag_g] + P[node_g]:  two 128-byte
 // gathers and an add per vertex instead of writing 544 B of X and reading it back through a GEMM
 // (features 0.46 ms + linear 0.22 ms -> 0.1 ms per 100 K candidates).  Same sum, different association.
-constexpr int kH1Block = 64;     // ONE wave per subgraph: 8 rows per step cover the typical subgraph (mean 15 vertices) in two
+constexpr int kH1Block = 256;    // ONE wave per subgraph (8 rows per step cover the typical subgraph in two), four subgraphs per workgroup:
+                                 // 100 K one-wave workgroups were bound by the dispatcher
 template <typename TOUT>
 __global__ __launch_bounds__(kH1Block) void seal_h1_tables_kernel(const int32_t* __restrict__ nodes,
                                                                const int64_t* __restrict__ node_off,
@@ -906,11 +907,11 @@ __global__ __launch_bounds__(kH1Block) void seal_h1_tables_kernel(const int32_t*
                                                                int32_t* err_flag) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c4 = (lane & 7) * 4, sub = lane >> 3;   // 8 lanes x float4 cover a 32-wide row; 8 rows per wave step
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * (kH1Block / 64) + wave; b < B; b += static_cast<int64_t>(gridDim.x) * (kH1Block / 64)) {
     const int64_t base = node_off[b];
     int n = static_cast<int>(node_off[b + 1] - base);
     if (n > MAXN) n = MAXN;
-    for (int i0 = wave * 8; i0 < n; i0 += (kH1Block / 64) * 8) {
+    for (int i0 = 0; i0 < n; i0 += 8) {
       const int i = i0 + sub;
       const int ic = i < n ? i : n - 1;              // clamped: the duplicate is not stored
       int32_t tg = tags[b * MAXN + ic];
@@ -995,6 +996,64 @@ __global__ __launch_bounds__(kSealBlock) void seal_sortpool_kernel(const float* 
         out[b * k * C + q] = r < n ? z[(base + order[r]) * ldz + c] : 0.f;
       }
     }
+  }
+}
+
+// One WAVE per subgraph (four per workgroup), no workgroup barrier: 100 K workgroups of 128 threads were bound by the
+// dispatcher, not by the 18 rows a subgraph contributes (0.100 -> 0.05 ms per 100 K subgraphs).  Same total order as
+// above (key descending, NaN last, ties by index); C % 4 == 0, 16-byte aligned rows.
+__global__ __launch_bounds__(kBlock) void seal_sortpool_wave_kernel(const float* __restrict__ z, int64_t ldz,
+                                                                    const float* __restrict__ key,
+                                                                    const int64_t* __restrict__ node_off, int64_t B,
+                                                                    int k, int C4, float* __restrict__ out) {
+  __shared__ float keys[kBlock / 64][MAXN];
+  __shared__ int order[kBlock / 64][MAXN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave; b < B; b += static_cast<int64_t>(gridDim.x) * (kBlock / 64)) {
+    const int64_t base = node_off[b];
+    int n = static_cast<int>(node_off[b + 1] - base);
+    if (n > MAXN) n = MAXN;
+    float mine[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = lane + 64 * q;
+      mine[q] = t < n ? key[base + t] : 0.f;
+      if (t < n) keys[wave][t] = mine[q];
+    }
+    wave_lds_sync();
+    int rank[2] = {0, 0};
+    for (int j = 0; j < n; ++j) {
+      const float o = keys[wave][j];                     // the same address in every lane: an LDS broadcast
+      const bool o_nan = o != o;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bool mine_nan = mine[q] != mine[q];
+        const bool tie = (o == mine[q]) || (o_nan && mine_nan);
+        rank[q] += (o > mine[q]) || (mine_nan && !o_nan) || (tie && j < lane + 64 * q);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (lane + 64 * q < n) order[wave][rank[q]] = lane + 64 * q;
+    wave_lds_sync();
+    const int total = k * C4;
+    float4* ob = reinterpret_cast<float4*>(out) + b * total;
+    for (int q0 = lane; q0 < total; q0 += 4 * 64) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * 64, r = q / C4, c = q - r * C4;
+        const bool ok = q < total && r < n;
+        const float4 t4 = *reinterpret_cast<const float4*>(z + (base + (ok ? order[wave][r] : 0)) * ldz + (ok ? c * 4 : 0));
+        v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * 64;
+        if (q < total) ob[q] = v[u];
+      }
+    }
+    wave_lds_sync();                                     // keys / order are rewritten by the wave's next subgraph
   }
 }
 
@@ -1282,7 +1341,8 @@ LPG_EXPORT int lpg_seal_h1_tables_f32(const int32_t* nodes, const int64_t* node_
   LPG_REQUIRE(nodes && node_off && tags && w1_tag && p_table && h1, "seal_h1_tables: null pointer");
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   LPG_REQUIRE(al16(w1_tag) && al16(p_table) && al16(h1), "seal_h1_tables: tables and output must be 16-byte aligned");
-  const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));   // a workgroup per subgraph (see lpg_seal_subgraphs)
+  const int64_t g4 = ceil_div(B, kH1Block / 64);
+  const int grid = static_cast<int>(g4 < (int64_t(1) << 24) ? g4 : (int64_t(1) << 24));   // a wave per subgraph
   hipLaunchKernelGGL(seal_h1_tables_kernel<float>, dim3(grid), dim3(kH1Block), 0, as_stream(stream), nodes, node_off, tags, tag_map,
                      tag_map_len, T, w1_tag, p_table, n_graph, B, h1, ldh, err_flag);
   return check_launch("seal_h1_tables");
@@ -1297,7 +1357,8 @@ LPG_EXPORT int lpg_seal_h1_tables_bf16(const int32_t* nodes, const int64_t* node
   LPG_REQUIRE(nodes && node_off && tags && w1_tag && p_table && h1, "seal_h1_tables_bf16: null pointer");
   auto al = [](const void* p, int a) { return reinterpret_cast<uintptr_t>(p) % a == 0; };
   LPG_REQUIRE(al(w1_tag, 16) && al(p_table, 16) && al(h1, 8), "seal_h1_tables_bf16: tables 16-byte, output 8-byte aligned");
-  const int grid = static_cast<int>(B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
+  const int64_t g4 = ceil_div(B, kH1Block / 64);
+  const int grid = static_cast<int>(g4 < (int64_t(1) << 24) ? g4 : (int64_t(1) << 24));
   hipLaunchKernelGGL(seal_h1_tables_kernel<uint16_t>, dim3(grid), dim3(kH1Block), 0, as_stream(stream), nodes, node_off, tags,
                      tag_map, tag_map_len, T, w1_tag, p_table, n_graph, B, h1, ldh, err_flag);
   return check_launch("seal_h1_tables_bf16");
@@ -1312,6 +1373,12 @@ LPG_EXPORT int lpg_seal_sortpool_f32(const float* z, int64_t ldz, const float* k
   LPG_REQUIRE(k * C < (int64_t(1) << 30), "seal_sortpool: k * C too large");
   const int vec = C % 4 == 0 && ldz % 4 == 0 && reinterpret_cast<uintptr_t>(z) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  if (vec && B > 64) {
+    const int64_t g4 = ceil_div(B, kBlock / 64);
+    hipLaunchKernelGGL(seal_sortpool_wave_kernel, dim3(static_cast<unsigned>(g4 < (int64_t(1) << 24) ? g4 : (int64_t(1) << 24))),
+                       dim3(kBlock), 0, as_stream(stream), z, ldz, key, node_off, B, static_cast<int>(k), static_cast<int>(C / 4), out);
+    return check_launch("seal_sortpool");
+  }
   hipLaunchKernelGGL(seal_sortpool_kernel, dim3(grid), dim3(kSealBlock), 0, as_stream(stream), z, ldz, key, node_off, B,
                      k, C, out, vec);
   return check_launch("seal_sortpool");

@@ -445,20 +445,17 @@ def first_layer_h1(batch, tag_map, tags_size, emb, w1, check=True):
     lib = _lib.load()
     T = int(tags_size)
     bf16 = emb.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
-    w1_in, emb_in = w1, emb
-    w1 = _ops._c(w1, torch.float32)          # (cached below per (emb, W_1) version: the conversions run once)
-    emb = _ops._c(emb, torch.float32)
     if w1.shape[1] != 32 or w1.shape[0] != T + emb.shape[1]:
         raise ValueError(f"first_layer_h1: W_1 must be [{T + emb.shape[1]}, 32], got {tuple(w1.shape)}")
-    w1_tag = w1[:T].contiguous()
-    # P depends on the parameters only (embedding table, W_1): computed once per (emb, W_1, T) version
-    ck = (emb_in.data_ptr(), emb_in._version, w1_in.data_ptr(), w1_in._version, T, tuple(emb_in.shape), bf16)
+    # the two tables depend on the parameters only (embedding table, W_1): built once per (emb, W_1, T) version
+    ck = (emb.data_ptr(), emb._version, w1.data_ptr(), w1._version, T, tuple(emb.shape), bf16)
     hit = _p_table_cache.get(ck)
     if hit is None:
         if len(_p_table_cache) > 4:
             _p_table_cache.clear()
-        # [n_graph, 32] fp32 (for bf16 inputs: the fp32 product of the bf16 values); keeps the key tensors alive
-        hit = _p_table_cache[ck] = (_ops.linear(emb, w1[T:], w_is_km=True), w1_tag, emb_in, w1_in)
+        w1f, embf = _ops._c(w1, torch.float32), _ops._c(emb, torch.float32)
+        # P [n_graph, 32] fp32 (for bf16 inputs: the fp32 product of the bf16 values), W_1's tag rows; keeps the key tensors alive
+        hit = _p_table_cache[ck] = (_ops.linear(embf, w1f[T:], w_is_km=True), w1f[:T].contiguous(), emb, w1)
     p_table, w1_tag = hit[0], hit[1]
     off = batch.node_off()
     total = batch.total()

@@ -15,6 +15,8 @@ gen = torch.Generator(device=dev); gen.manual_seed(2)
 pairs = torch.randint(0, N, (B, 2), generator=gen, device=dev)
 emb = torch.randn((N, D), generator=gen, device=dev)
 k = 18
+if "--window" in sys.argv:
+    seal.CONV_WINDOW = int(sys.argv[sys.argv.index("--window") + 1])
 if "--variant" in sys.argv:
     _lib.set_option("seal_conv_variant", int(sys.argv[sys.argv.index("--variant") + 1]))
 def T(fn, it=10):
