@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restric
       }
     }
     if constexpr (VEC == 4)
-      *reinterpret_cast<float4*>(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+      store_stream(y + i, make_float4(o[0], o[1], o[2], o[3]));
     else
       y[i] = o[0];
   }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void gn_apply_rows4_kernel(const float* __r
                              (v[u].w - sh.w) * sc.w + bi.w);
       if (relu) o = make_float4(o.x > 0.f ? o.x : 0.f, o.y > 0.f ? o.y : 0.f, o.z > 0.f ? o.z : 0.f, o.w > 0.f ? o.w : 0.f);
       if (add_to) o = make_float4(o.x + a[u].x, o.y + a[u].y, o.z + a[u].z, o.w + a[u].w);
-      if (i < n) *reinterpret_cast<float4*>(y + i * d + 4 * cv) = o;
+      if (i < n) store_stream(y + i * d + 4 * cv, o);
     }
   }
 }

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void pair_mul_kernel(const float* __restric
 // Row-tiled forms for d = 4 * 2^k <= 1024 (every width the models use): a thread keeps ONE column chunk and walks rows,
 // so the (row, column) split is computed once instead of a 64-bit division per element, and four rows are in flight
 // per thread -- all index loads, then all row loads from clamped addresses, then the stores.
-constexpr int kRowsU = 4;
+constexpr int kRowsU = 8;
 __global__ __launch_bounds__(kBlock) void embedding_rows4_kernel(const float* __restrict__ table, int64_t n_rows,
                                                                  int64_t d, int dv, const int64_t* __restrict__ idx,
                                                                  int64_t n, float* __restrict__ out, int32_t* err_flag) {
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void embedding_rows4_kernel(const float* __
     }
 #pragma unroll
     for (int u = 0; u < kRowsU; ++u)
-      if (ok[u]) *reinterpret_cast<float4*>(out + (base + u * rpb + rin) * d + 4 * cv) = v[u];
+      if (ok[u]) store_stream(out + (base + u * rpb + rin) * d + 4 * cv, v[u]);
   }
 }
 
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(kBlock) void pair_mul_rows4_kernel(const float* __r
 #pragma unroll
     for (int u = 0; u < kRowsU; ++u)
       if (ok[u])
-        *reinterpret_cast<float4*>(h + (base + u * rpb + rin) * d + 4 * cv) =
-            make_float4(va[u].x * vb[u].x, va[u].y * vb[u].y, va[u].z * vb[u].z, va[u].w * vb[u].w);
+        store_stream(h + (base + u * rpb + rin) * d + 4 * cv,
+                     make_float4(va[u].x * vb[u].x, va[u].y * vb[u].y, va[u].z * vb[u].z, va[u].w * vb[u].w));
   }
 }
 

@@ -79,7 +79,13 @@ def _c(t, dtype=None):
 
 # ------------------------------------------------------------------------------ scatter_add
 DEGREE_SORT_MIN = 1 << 21           # entries from which int64 histograms take the atomic-free path of csrc/degree.hip
-SCATTER_SORT_MIN = 1 << 20          # entries from which float32 row scatters group by destination instead of using atomics
+# entries from which float32 row scatters group by destination instead of using float atomics.  Measured
+# (profiles/scatter_crossover.py -> profiles/r02/scatter_crossover.log, N = E / 10): with the grouping memoised -- a GNN
+# calls with the same index tensor every layer and every step -- the grouped route is never slower from 2^13 rows and
+# 1.4x (2^16) to 3.4x (2^21) faster at d = 128; a FIRST call on a new index tensor also pays the grouping (0.11-0.17 ms
+# up to 2^19 rows, one host sync) and only wins outright from E * d ~ 2^27 elements.  2^16: from there the steady state
+# wins clearly, every sum is bitwise reproducible (entry order), and the one-time grouping is ~2 call times.
+SCATTER_SORT_MIN = 1 << 16
 
 
 def scatter_add_sorts(E, d, dtype):

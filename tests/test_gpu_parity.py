@@ -130,7 +130,7 @@ def test_degree_sorted_path_bit_exact(dev, n, monkeypatch):
     with pytest.raises(IndexError):
         ops.degree(bad, n)
     lib = lpgnn_amd.load_library()
-    assert lib.lpg_degree_i64_bytes(E, n) > 8 * E and lib.lpg_degree_i64_bytes(-1, 5) < 0
+    assert lib.lpg_degree_i64_bytes(E, n) > 2 * E and lib.lpg_degree_i64_bytes(-1, 5) < 0
 
 
 def test_scatter_add_variants(dev):
