@@ -173,6 +173,12 @@ int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w_is_km, con
 int lpg_linear_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, int w_is_km, const float* bias,
                     int act, uint16_t* y, int64_t ldy, int64_t n, int64_t k, int64_t m, void* stream);
 
+/* Row-wise LayerNorm: y = (x - mean) / sqrt(var + eps) [* weight + bias] [ReLU], biased variance over the d columns
+ * of each row -- torch.nn.LayerNorm(d, elementwise_affine=False) of LocalWLNet's node-feature branch
+ * (relu_lin, TwoWL/model/model.py:28-33,47-51).  weight / bias may be NULL.  d <= 1024. */
+int lpg_layernorm_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t d, float eps, const float* weight,
+                           const float* bias, int relu, float* y, int64_t ldy, void* stream);
+
 /* ---------------------------------------------------------------- GraphNorm (K6)
  * torch_geometric.nn.GraphNorm.forward(x, batch=None) [TwoWL/model/model.py:38,54]:
  * o = x - mean*mean_scale; y = weight*o/sqrt(mean(o^2)+eps) + bias, column-wise over all n rows;
@@ -291,18 +297,21 @@ int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8
  * per row) and rowptr.  col capacity col_cap >= 2 * n_pairs; rowptr[n_nodes] = nnz stays on the device; out-of-range
  * pairs are flagged and dropped.  No host sync. */
 int64_t lpg_seal_train_csr_bytes(int64_t n_pairs, int64_t n_nodes);
-int lpg_seal_train_csr(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, int64_t* rowptr, int32_t* col,
-                       int64_t col_cap, void* workspace, int64_t workspace_bytes, int32_t* err_flag, void* stream);
+int lpg_seal_train_csr(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, int directed,
+                       int64_t* rowptr, int32_t* col, int64_t col_cap, void* workspace,
+                       int64_t workspace_bytes, int32_t* err_flag, void* stream);
 
 /* The train-positive graph `A` / `G` of SEAL (SEAL/config/subgraph.py:27-31,70-72) for SMALL graphs
  * (n_nodes <= lpg_seal_train_csr_small_max_nodes() = 8192; fb-pages-food has 620): symmetric, neighbours ascending
  * and unique per row, self loops kept.  pairs [n_pairs, 2] int64 (the train positives); `bits` = scratch of
  * n_nodes * ceil(n_nodes / 32) * 4 bytes (zeroed by the call); rowptr [n_nodes + 1]; col capacity col_cap >=
- * 2 * n_pairs.  Three launches, no host sync (rowptr[n_nodes] = nnz stays on the device). */
+ * 2 * n_pairs.  Three launches, no host sync (rowptr[n_nodes] = nnz stays on the device).
+ * directed != 0 (network_type = 1, SEAL/config/subgraph.py:29-31: A set in ONE orientation, nx.DiGraph): rows list
+ * successors only. */
 int64_t lpg_seal_train_csr_small_max_nodes(void);
-int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, void* bits,
-                             int64_t bits_bytes, int64_t* rowptr, int32_t* col, int64_t col_cap,
-                             int32_t* err_flag, void* stream);
+int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, int directed,
+                             void* bits, int64_t bits_bytes, int64_t* rowptr, int32_t* col,
+                             int64_t col_cap, int32_t* err_flag, void* stream);
 
 /* ---------------------------------------------------------------- SEAL structure path (a10-a12)
  * Batched 0/1-hop enclosing subgraphs + DRNL labels on the train graph given as a symmetric CSR
@@ -324,7 +333,10 @@ int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, int64_t n_no
  * One launch, two kinds of workgroup: a pair whose two neighbour lists hold <= 62 entries together (n <= 64, the
  * cap cannot fire: most of a batch) is handled by ONE 64-lane wave (two pairs per workgroup, no workgroup barrier); every
  * other pair by the 128 threads of a workgroup that owns 8 consecutive pairs.  Same outputs bit for bit either way;
- * option "seal_pair_small" = 0 (or replay) gives every pair a 128-thread workgroup. */
+ * option "seal_pair_small" = 0 (or replay) gives every pair a 128-thread workgroup.
+ * directed != 0 (network_type = 1): adj_rowptr / adj_col list SUCCESSORS (lpg_seal_train_csr*(directed = 1)); the
+ * neighbour sets are successor sets (nx.neighbors of a DiGraph), the induced adjacency is not symmetric and the DRNL
+ * distances are directed shortest paths from either target (SEAL/utils/utils.py:38); always the workgroup form. */
 #define LPG_SEAL_MAXN 128
 #define LPG_SEAL_TAG_BOUND (1 + 127 + 127 * 127)
 int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_t n_graph_nodes,
@@ -332,7 +344,7 @@ int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_
                        int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes,
                        int32_t* tags, uint32_t* adj_bits, uint8_t* capped, uint8_t* tag_present,
                        const int32_t* hub_index, const uint32_t* hub_bits, int64_t hub_words,
-                       int32_t* err_flag, void* stream);
+                       int directed, int32_t* err_flag, void* stream);
 /* Block-diagonal CSR of A~ = A + I over a batch, D^-1 = 1/rowsum(A~), and
  * X = [onehot(tag_map[tag], T) || emb[node]]  [SEAL/config/data.py:94-140].
  * node_off[B+1] = exclusive scan of n_nodes (host-computed or torch.cumsum);

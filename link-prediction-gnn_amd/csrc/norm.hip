@@ -315,6 +315,62 @@ inline int part_blocks(int64_t n, int64_t* rows_per_block) {
 }
 }  // namespace
 
+// ---- row-wise LayerNorm (the use_node_feat branch of LocalWLNet, TwoWL/model/model.py:28-33,47-51) ---------------
+// torch.nn.LayerNorm(d, elementwise_affine=False): y = (x - mean) / sqrt(var + eps), biased variance over the d columns
+// of each row.  One wave per row; the row stays in registers between the mean and the variance pass (d <= 64 * kLnMax).
+namespace {
+constexpr int kLnMax = 16;                           // columns per lane held in registers: d <= 1024
+__global__ __launch_bounds__(kBlock) void layernorm_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int d,
+                                                                float eps, const float* __restrict__ weight,
+                                                                const float* __restrict__ bias, int relu,
+                                                                float* __restrict__ y, int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  if (row >= n) return;                              // wave-uniform
+  float v[kLnMax];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMax; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < d ? x[row * ldx + c] : 0.f;
+    s += v[i];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / static_cast<float>(d);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMax; ++i) {
+    const float dv = lane + 64 * i < d ? v[i] - mean : 0.f;
+    q += dv * dv;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / static_cast<float>(d) + eps);
+#pragma unroll
+  for (int i = 0; i < kLnMax; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d) {
+      float o = (v[i] - mean) * rstd;
+      if (weight) o *= weight[c];
+      if (bias) o += bias[c];
+      if (relu) o = o > 0.f ? o : 0.f;
+      y[row * ldy + c] = o;
+    }
+  }
+}
+}  // namespace
+
+LPG_EXPORT int lpg_layernorm_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t d, float eps, const float* weight,
+                                      const float* bias, int relu, float* y, int64_t ldy, void* stream) {
+  LPG_REQUIRE(n >= 0 && d >= 1 && d <= 64 * kLnMax && ldx >= d && ldy >= d, "layernorm_rows: needs 1 <= d <= %d", 64 * kLnMax);
+  if (n == 0) return LPG_OK;
+  LPG_REQUIRE(x && y, "layernorm_rows: null pointer");
+  hipLaunchKernelGGL(layernorm_rows_kernel, dim3(static_cast<unsigned>(ceil_div(n, kBlock / 64))), dim3(kBlock), 0,
+                     as_stream(stream), x, ldx, n, static_cast<int>(d), eps, weight, bias, relu, y, ldy);
+  return check_launch("layernorm_rows");
+}
+
 LPG_EXPORT int64_t lpg_graphnorm_bytes(int64_t n, int64_t d) {
   if (n < 0 || d < 1) return LPG_E_INVALID;
   return static_cast<int64_t>(kMaxPartBlocks) * 2 * d * 8 + lpg::align_up(3 * d * 4, 256) + 256;

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     int64_t B, int hop, int max_nb, int replay, int cap_policy, uint64_t seed, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
     int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag,
     uint8_t* __restrict__ tag_present, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
-    int hub_words, int fused) {
+    int hub_words, int fused, int directed) {
+  // directed != 0 (SEAL/config/subgraph.py:30-31,69 with network_type = 1): the CSR lists SUCCESSORS only and the induced
+  // adjacency is not symmetric -- no entry is mirrored, and rows that are not streamed are searched against every column.
   // fused == 0: workgroup w takes pairs w, w + gridDim.x, ... with all 128 threads (every pair; replayed node lists).
   // fused != 0: ONE launch, two kinds of workgroup.  The first ceil(B / kDeferGroup) workgroups each own kDeferGroup
   // consecutive pairs and handle, with all 128 threads, those that do not fit a wave (long neighbour lists, the cap);
@@ -609,8 +611,8 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
           // the adjacency is symmetric (ABI contract): every hit also sets its mirror entry, which is how the
           // rows of hubs get filled without ever touching their lists
           const uint32_t ibit = 1u << (i & 31);
-          if (xv == u && i != 1) { atomicOr(&adj[i][0], 1u); atomicOr(&adj[0][i >> 5], ibit); }   // (1,0) is a target entry
-          if (xv == v && i != 0) { atomicOr(&adj[i][0], 2u); atomicOr(&adj[1][i >> 5], ibit); }   // (0,1) likewise
+          if (xv == u && i != 1) { atomicOr(&adj[i][0], 1u); if (!directed) atomicOr(&adj[0][i >> 5], ibit); }   // (1,0) is a target entry
+          if (xv == v && i != 0) { atomicOr(&adj[i][0], 2u); if (!directed) atomicOr(&adj[1][i >> 5], ibit); }   // (0,1) likewise
           if (xv != u && xv != v) {
             const uint32_t hsh = (static_cast<uint32_t>(xv) * 0x9E3779B1u) >> 20;
             if (!((member[hsh >> 5] >> (hsh & 31)) & 1u)) continue;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
             }
             if (lo < n && nodes[lo] == xv) {
               atomicOr(&adj[i][lo >> 5], 1u << (lo & 31));
-              atomicOr(&adj[lo][i >> 5], ibit);
+              if (!directed) atomicOr(&adj[lo][i >> 5], ibit);
             }
           }
         }
@@ -632,12 +634,13 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     // a wave of occupancy in registers and lost more on the common small subgraphs than it won on the hub-rich ones): a hub-rich
     // subgraph has ~30 hubs = 1000 searches of ~12 dependent probes each, 8 per thread back to back before.
     // Without a replayed list only a <= b of the (symmetric) hub x hub block is searched and mirrored.
-    const int nbig = s_nbig, ncol = replay ? n : nbig;
+    const bool allcols = replay || directed;          // no symmetry to lean on: a big row is searched against every column
+    const int nbig = s_nbig, ncol = allcols ? n : nbig;
     // With the graph's hub bit matrix (hub_index[node] = its row, -1 for a node that is not a hub; one bit per hub
     // pair) a hub x hub entry is two index loads and one word instead of a ~12-probe binary search in a list of
     // thousands.  A big row whose node has no hub index (tables built with another threshold) falls back to the search.
     bool search = true;
-    if (hub_index && !replay) {
+    if (hub_index && !allcols) {
       if (t == 0) s_search = 0;
       __syncthreads();
       for (int p = t; p < nbig * nbig; p += kSealBlock) {
@@ -665,8 +668,8 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
         const bool valid = p < nbig * ncol;
         const int a = valid ? p / ncol : 0, b2 = valid ? p % ncol : 0;
         ii[q] = big[a];
-        jj[q] = replay ? b2 : big[b2];
-        const bool take = valid && (replay || a <= b2);
+        jj[q] = allcols ? b2 : big[b2];
+        const bool take = valid && (allcols || a <= b2);
         row[q] = col + rbase[ii[q]];
         len[q] = take ? rdeg[ii[q]] : 0;
         key[q] = nodes[jj[q]];
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
         const int i = ii[q], j = jj[q];
         if (lo[q] < len[q] && fv[q] == key[q] && !((i == 0 && j == 1) || (i == 1 && j == 0))) {
           atomicOr(&adj[i][j >> 5], 1u << (j & 31));
-          if (!replay) atomicOr(&adj[j][i >> 5], 1u << (i & 31));
+          if (!allcols) atomicOr(&adj[j][i >> 5], 1u << (i & 31));
         }
       }
     }
@@ -1238,7 +1241,7 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
                                   const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
                                   int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits, uint8_t* capped,
                                   uint8_t* tag_present, const int32_t* hub_index, const uint32_t* hub_bits,
-                                  int64_t hub_words, int32_t* err_flag, void* stream) {
+                                  int64_t hub_words, int directed, int32_t* err_flag, void* stream) {
   LPG_REQUIRE(B >= 0 && n_graph_nodes >= 0, "seal_subgraphs: bad sizes");
   LPG_REQUIRE(hop == 0 || hop == 1, "seal_subgraphs: hop must be 0 or 1 (the reference itself fails for hop >= 2)");
   LPG_REQUIRE(max_neighbors >= 2 && max_neighbors <= MAXN, "seal_subgraphs: max_neighbors must be in [2, %d]", MAXN);
@@ -1246,7 +1249,7 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   LPG_REQUIRE(adj_rowptr && pairs && nodes && n_nodes && tags && adj_bits && capped, "seal_subgraphs: null pointer");
   hipStream_t st = as_stream(stream);
   const int32_t* hidx = hub_bits ? hub_index : nullptr;
-  const bool fused = !replay && options().seal_pair_small && B < (int64_t(1) << 30) &&
+  const bool fused = !replay && !directed && options().seal_pair_small && B < (int64_t(1) << 30) &&
                      reinterpret_cast<uintptr_t>(adj_bits) % 16 == 0;
   // fused: ceil(B / 8) workgroups for the pairs that need 128 threads, then one WAVE per pair (two per workgroup) for
   // the rest -- most of a batch.  Otherwise a workgroup per pair (the hardware dispatcher is the work queue: a static
@@ -1254,7 +1257,7 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   const int64_t grid = fused ? ceil_div(B, kDeferGroup) + ceil_div(B, kSealBlock / 64) : (B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
   hipLaunchKernelGGL(seal_subgraph_kernel, dim3(static_cast<unsigned>(grid)), dim3(kSealBlock), 0, st, adj_rowptr, adj_col,
                      n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag,
-                     tag_present, hidx, hub_bits, static_cast<int>(hub_words), fused ? 1 : 0);
+                     tag_present, directed ? nullptr : hidx, hub_bits, static_cast<int>(hub_words), fused ? 1 : 0, directed);
   return check_launch("seal_subgraphs");
 }
 

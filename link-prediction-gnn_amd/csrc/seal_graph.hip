@@ -16,7 +16,8 @@ constexpr int kMaxNodes = 8192;
 constexpr int kScanBlock = 1024;
 
 __global__ __launch_bounds__(kBlock) void tg_set_bits_kernel(const int64_t* __restrict__ pairs, int64_t n_pairs, int n,
-                                                             int words, uint32_t* __restrict__ bits, int32_t* err_flag) {
+                                                             int words, uint32_t* __restrict__ bits, int32_t* err_flag,
+                                                             int directed) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_pairs; i += stride) {
     const int64_t u = pairs[2 * i], v = pairs[2 * i + 1];
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(kBlock) void tg_set_bits_kernel(const int64_t* __re
       continue;
     }
     atomicOr(&bits[u * words + (v >> 5)], 1u << (v & 31));
-    atomicOr(&bits[v * words + (u >> 5)], 1u << (u & 31));
+    if (!directed) atomicOr(&bits[v * words + (u >> 5)], 1u << (u & 31));     // (SEAL/config/subgraph.py:30-31)
   }
 }
 
@@ -107,7 +108,7 @@ inline unsigned key_bits(int64_t n) {                       // bits of the large
 }
 
 __global__ __launch_bounds__(kBlock) void tg_keys_kernel(const int64_t* __restrict__ pairs, int64_t P, int64_t n,
-                                                         uint64_t* __restrict__ keys, int32_t* err_flag) {
+                                                         uint64_t* __restrict__ keys, int32_t* err_flag, int directed) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < P; i += stride) {
     const int64_t u = pairs[2 * i], v = pairs[2 * i + 1];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void tg_keys_kernel(const int64_t* __restri
     if (!ok) flag_error(err_flag, LPG_F_INDEX_RANGE);
     const uint64_t drop = static_cast<uint64_t>(n) * static_cast<uint64_t>(n);
     keys[2 * i] = ok ? static_cast<uint64_t>(u) * n + v : drop;
-    keys[2 * i + 1] = ok ? static_cast<uint64_t>(v) * n + u : drop;
+    keys[2 * i + 1] = ok && !directed ? static_cast<uint64_t>(v) * n + u : drop;
   }
 }
 
@@ -175,7 +176,7 @@ TgWs tg_carve(void* ws, int64_t P, int64_t n) {
 
 LPG_EXPORT int64_t lpg_seal_train_csr_small_max_nodes(void) { return kMaxNodes; }
 
-LPG_EXPORT int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, void* bits,
+LPG_EXPORT int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, int directed, void* bits,
                                         int64_t bits_bytes, int64_t* rowptr, int32_t* col, int64_t col_cap,
                                         int32_t* err_flag, void* stream) {
   LPG_REQUIRE(n_pairs >= 0 && n_nodes >= 1 && n_nodes <= kMaxNodes && col_cap >= 0,
@@ -190,7 +191,7 @@ LPG_EXPORT int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, i
   LPG_HIP(hipMemsetAsync(bits, 0, static_cast<size_t>(n) * words * 4, st));
   uint32_t* b = static_cast<uint32_t*>(bits);
   if (n_pairs > 0)
-    hipLaunchKernelGGL(tg_set_bits_kernel, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, pairs, n_pairs, n, words, b, err_flag);
+    hipLaunchKernelGGL(tg_set_bits_kernel, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, pairs, n_pairs, n, words, b, err_flag, directed);
   hipLaunchKernelGGL(tg_rowptr_kernel, dim3(1), dim3(kScanBlock), 0, st, b, n, words, rowptr);
   hipLaunchKernelGGL(tg_fill_kernel, dim3(grid_for(static_cast<int64_t>(n) * 64)), dim3(kBlock), 0, st, b, n, words, rowptr,
                      col, col_cap);
@@ -202,8 +203,8 @@ LPG_EXPORT int64_t lpg_seal_train_csr_bytes(int64_t n_pairs, int64_t n_nodes) {
   return tg_carve(nullptr, n_pairs, n_nodes).total;
 }
 
-LPG_EXPORT int lpg_seal_train_csr(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, int64_t* rowptr, int32_t* col,
-                                  int64_t col_cap, void* workspace, int64_t workspace_bytes, int32_t* err_flag,
+LPG_EXPORT int lpg_seal_train_csr(const int64_t* pairs, int64_t n_pairs, int64_t n_nodes, int directed, int64_t* rowptr,
+                                  int32_t* col, int64_t col_cap, void* workspace, int64_t workspace_bytes, int32_t* err_flag,
                                   void* stream) {
   LPG_REQUIRE(n_pairs >= 0 && n_pairs < (int64_t(1) << 30) && n_nodes >= 1 && n_nodes < (int64_t(1) << 31) && col_cap >= 0,
               "seal_train_csr: bad sizes");
@@ -217,7 +218,7 @@ LPG_EXPORT int lpg_seal_train_csr(const int64_t* pairs, int64_t n_pairs, int64_t
   const int64_t M = 2 * n_pairs;
   LPG_HIP(hipMemsetAsync(w.count, 0, 8, st));
   if (M > 0) {
-    hipLaunchKernelGGL(tg_keys_kernel, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, pairs, n_pairs, n_nodes, w.keys, err_flag);
+    hipLaunchKernelGGL(tg_keys_kernel, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, pairs, n_pairs, n_nodes, w.keys, err_flag, directed);
     size_t tmp = w.tmp_bytes;
     LPG_HIP(rocprim::radix_sort_keys(w.tmp, tmp, w.keys, w.sorted, static_cast<size_t>(M), 0u, key_bits(n_nodes), st, false));
     tmp = w.tmp_bytes;

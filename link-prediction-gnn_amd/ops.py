@@ -381,6 +381,19 @@ def linear(x, weight, bias=None, w_is_km=False, out=None, act=None, n=None, ldx=
     return out
 
 
+def layer_norm_rows(x, eps=1e-5, weight=None, bias=None, relu=False):
+    """torch.nn.LayerNorm over the last dimension of a [n, d] float32 tensor (d <= 1024), optional affine and ReLU"""
+    lib = _lib.load()
+    _need_gpu(x, weight, bias)
+    x = _c(x, torch.float32)
+    n, d = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib.lpg_layernorm_rows_f32(_ptr(x), x.stride(0), n, d, float(eps), _ptr(_c(weight, torch.float32)),
+                                          _ptr(_c(bias, torch.float32)), int(relu), _ptr(y), y.stride(0), _stream()),
+               "layernorm_rows")
+    return y
+
+
 _gn_ws = {}
 
 

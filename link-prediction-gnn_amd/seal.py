@@ -25,8 +25,9 @@ class TrainGraph:
     """symmetric 0/1 adjacency of the train-positive graph as a CSR with ascending, unique
     columns per row (self loops kept) -- the `A` / `G` of SEAL/config/subgraph.py:27-31,70-72."""
 
-    def __init__(self, rowptr, col, n_nodes):
+    def __init__(self, rowptr, col, n_nodes, directed=False):
         self.rowptr, self.col, self.n_nodes = rowptr, col, int(n_nodes)
+        self.directed = bool(directed)               # network_type = 1: rows list successors only (nx.DiGraph)
         self.hub_index = self.hub_bits = None        # hub bit matrix (build_hub_matrix): hub x hub adjacency in one load
 
     HUB_DEGREE = 256                                 # the extraction kernel streams shorter neighbour lists
@@ -37,8 +38,8 @@ class TrainGraph:
         are adjacent; hubs = nodes with more than HUB_DEGREE neighbours.  Skipped for graphs with more than
         MAX_HUBS of them or fewer than 128 K stored edges (the kernel then binary-searches hub x hub entries as before)."""
         dev = self.rowptr.device
-        if self.col.numel() < (1 << 17):             # small graphs (fb-pages-food): no host sync, the few searches are cheap
-            return self
+        if self.directed or self.col.numel() < (1 << 17):   # directed: no symmetry for the kernel to lean on; small graphs
+            return self                                     # (fb-pages-food): no host sync, the few searches are cheap
         deg = self.rowptr[1:] - self.rowptr[:-1]
         hubs = torch.nonzero(deg > self.HUB_DEGREE).flatten()
         H = int(hubs.numel())
@@ -63,8 +64,10 @@ class TrainGraph:
         return self
 
 
-def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
-    """positive: [P, 2] node pairs (numpy array or tensor, host or device); the last test_ratio of them are held out."""
+def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda", network_type=0):
+    """positive: [P, 2] node pairs (numpy array or tensor, host or device); the last test_ratio of them are held out.
+    network_type: 0 undirected (both orientations, SEAL/config/subgraph.py:29-31), 1 directed (row u lists v only)."""
+    directed = int(network_type) != 0
     if not torch.is_tensor(positive):
         positive = torch.from_numpy(np.ascontiguousarray(np.asarray(positive), dtype=np.int64))
     positive = positive.to(device=device, dtype=torch.int64)
@@ -79,11 +82,11 @@ def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
         bits = torch.empty(n_nodes * words, dtype=torch.int32, device=positive.device)
         rowptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=positive.device)
         col = torch.empty(max(2 * P, 1), dtype=torch.int32, device=positive.device)
-        _lib.check(lib.lpg_seal_train_csr_small(_ops._ptr(train_pos), P, n_nodes, _ops._ptr(bits), bits.numel() * 4,
+        _lib.check(lib.lpg_seal_train_csr_small(_ops._ptr(train_pos), P, n_nodes, int(directed), _ops._ptr(bits), bits.numel() * 4,
                                                 _ops._ptr(rowptr), _ops._ptr(col), col.numel(),
                                                 _ops._ptr(_ops.err_flag(positive.device)), _ops._stream()),
                    "seal_train_csr_small")
-        return TrainGraph(rowptr, col, n_nodes)      # (col's tail past rowptr[n] is unused capacity; hub matrix: n too small)
+        return TrainGraph(rowptr, col, n_nodes, directed)      # (col's tail past rowptr[n] is unused capacity; hub matrix: n too small)
     if positive.is_cuda:
         # any size: sorted, deduplicated 64-bit keys (row * n + col) -> col / rowptr, no host sync (csrc/seal_graph.hip)
         lib = _lib.load()
@@ -94,19 +97,19 @@ def build_train_csr(positive, n_nodes, test_ratio=0.1, device="cuda"):
         col = torch.empty(max(2 * P, 1), dtype=torch.int32, device=dev)
         nbytes = _lib.check(lib.lpg_seal_train_csr_bytes(P, n_nodes), "seal_train_csr_bytes")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.lpg_seal_train_csr(_ops._ptr(train_pos), P, n_nodes, _ops._ptr(rowptr), _ops._ptr(col), col.numel(),
+        _lib.check(lib.lpg_seal_train_csr(_ops._ptr(train_pos), P, n_nodes, int(directed), _ops._ptr(rowptr), _ops._ptr(col), col.numel(),
                                           _ops._ptr(ws), nbytes, _ops._ptr(_ops.err_flag(dev)), _ops._stream()),
                    "seal_train_csr")
-        return TrainGraph(rowptr, col, n_nodes).build_hub_matrix()
+        return TrainGraph(rowptr, col, n_nodes, directed).build_hub_matrix()
     # CPU tensors only (tests/test_seal_host.py checks the hub matrix's host logic on them): the same CSR through torch;
     # nothing downstream runs without a ROCm device (extract_subgraphs raises on CPU tensors)
     u, v = train_pos[:, 0], train_pos[:, 1]
-    keys = torch.unique(torch.cat([u * n_nodes + v, v * n_nodes + u]))       # sorted, deduplicated
+    keys = torch.unique(u * n_nodes + v if directed else torch.cat([u * n_nodes + v, v * n_nodes + u]))   # sorted, deduplicated
     rows = torch.div(keys, n_nodes, rounding_mode="floor")
     col = (keys - rows * n_nodes).to(torch.int32)
     rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=device)
     rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n_nodes), 0)
-    return TrainGraph(rowptr, col.contiguous(), n_nodes).build_hub_matrix()
+    return TrainGraph(rowptr, col.contiguous(), n_nodes, directed).build_hub_matrix()
 
 
 class SubgraphBatch:
@@ -212,13 +215,14 @@ def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, r
                                       _ops._ptr(tags), _ops._ptr(adj_bits), _ops._ptr(capped), _ops._ptr(present),
                                       _ops._ptr(graph.hub_index), _ops._ptr(graph.hub_bits),
                                       getattr(graph, "hub_words", 0) if graph.hub_bits is not None else 0,
-                                      _ops._ptr(_ops.err_flag(dev)), _ops._stream()), "seal_subgraphs")
+                                      int(getattr(graph, "directed", False)), _ops._ptr(_ops.err_flag(dev)), _ops._stream()),
+               "seal_subgraphs")
     # no sync of its own: the flag is read together with the batch's vertex total (SubgraphBatch.total(), which every
     # consumer needs first) or by the next checking op; out-of-range pairs were skipped, never dereferenced
     return SubgraphBatch(pairs, nodes, n, tags, adj_bits, capped, present)
 
 
-def _host_capped_nodes(pair, rowptr, col, max_neighbors, rng):
+def _host_capped_nodes(pair, rowptr, col, max_neighbors, rng):     # (rowptr / col: successors for a directed graph)
     """the reference's truncation branch (SEAL/config/subgraph.py:118-135, hop = 1) with an explicit
     numpy RandomState; only used for the few capped pairs."""
     u, v = int(pair[0]), int(pair[1])
@@ -293,9 +297,7 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
     the global compaction (:84-101) applied when features are built.
     cap_policy: "device" (default) or "host" -- the few pairs that hit the 100-node cap are rebuilt
     on the host with a seeded numpy RandomState walking the reference's own branch, then replayed."""
-    if network_type != 0:
-        raise NotImplementedError("the reference is run undirected (network_type=0)")
-    graph = build_train_csr(positive, nodes_size, test_ratio, device)
+    graph = build_train_csr(positive, nodes_size, test_ratio, device, network_type)
     if hop == "auto":
         hop = auto_hop(positive, negative, graph, test_ratio)
         if hop != 1:
@@ -612,10 +614,11 @@ def head(z, key, node_off, hw, a_all=None):
     return pre_y, score
 
 
-def score_links(positive, negative, nodes_size, emb, weights, head_weights, test_ratio=0.1, hop=1, device="cuda"):
+def score_links(positive, negative, nodes_size, emb, weights, head_weights, test_ratio=0.1, hop=1, device="cuda",
+                network_type=0):
     """the SEAL scoring forward end to end for a candidate set: structure (a10-a12), graph
     convolutions (a9) and the head.  Returns (scores [B], labels [B,1], batch)."""
-    batch, labels, T, tag_map, _ = link2subgraph(positive, negative, nodes_size, test_ratio, hop, device=device)
+    batch, labels, T, tag_map, _ = link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type, device=device)
     if emb is not None and _dense_ok(weights, weights[0].dtype) and emb.dtype == weights[0].dtype:   # X is never built: H_1 from two row gathers, then the dense stack
         k1 = head_weights["conv1d_kernel_1"]
         k1 = k1.reshape(-1, k1.shape[-1])
@@ -640,5 +643,6 @@ def score_links_from_file(path, emb, weights, head_weights, network_type=0, test
     positive, negative, n_nodes = _data.seal_load_data(path, network_type, seed)
     if emb is not None and emb.shape[0] != n_nodes:
         raise ValueError(f"score_links_from_file: emb has {emb.shape[0]} rows, the edge file has {n_nodes} nodes")
-    score, labels, batch = score_links(positive, negative, n_nodes, emb, weights, head_weights, test_ratio, hop, device)
+    score, labels, batch = score_links(positive, negative, n_nodes, emb, weights, head_weights, test_ratio, hop, device,
+                                       network_type)
     return score, labels, batch, (positive, negative, n_nodes)

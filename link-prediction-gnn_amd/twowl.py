@@ -99,15 +99,14 @@ def _tkey(t):
 
 
 class LocalWLNet(nn.Module):
-    """TwoWL/model/model.py:8-84 (degree-embedding variant, use_node_feat=False)."""
+    """TwoWL/model/model.py:8-84, both input branches: the degree embedding (use_node_feat=False: Embedding ->
+    GraphNorm, what fb-pages-food runs) and node features (use_node_feat=True: Dropout -> Linear -> LayerNorm without
+    affine -> Dropout, :28-33,47-51; state_dict keys lin1.1.0.weight / lin1.1.0.bias as in the reference)."""
 
     def __init__(self, max_x, use_node_feat=False, node_feat=None, channels_1wl=256, channels_2wl=32, depth1=1,
                  depth2=1, dp_lin0=0.7, dp_lin1=0.7, dp_emb=0.5, dp_1wl0=0.5, dp_2wl=0.5, dp_1wl1=0.5, act0=True,
                  act1=True):
         super().__init__()
-        if use_node_feat:
-            raise NotImplementedError("fb-pages-food has no node features; the reference path uses the "
-                                      "degree embedding (TwoWL/operators/datasets.py:107-114)")
 
         def relu_conv(insize, outsize, dp, act):
             return Seq([GCNConv(insize, outsize), GraphNorm(outsize), nn.Dropout(p=dp, inplace=True),
@@ -115,8 +114,14 @@ class LocalWLNet(nn.Module):
 
         self.max_x, self.use_node_feat, self.node_feat = max_x, use_node_feat, node_feat
         self._plan, self._plan_params = None, []
-        self.emb = nn.Sequential(nn.Embedding(max_x + 1, channels_1wl), GraphNorm(channels_1wl),
-                                 nn.Dropout(p=dp_emb, inplace=True))
+        if use_node_feat:
+            self.lin1 = nn.Sequential(nn.Dropout(dp_lin0),
+                                      nn.Sequential(nn.Linear(node_feat.shape[-1], channels_1wl),
+                                                    nn.LayerNorm(channels_1wl, elementwise_affine=False),
+                                                    nn.Dropout(p=dp_lin1, inplace=True), nn.Identity()))
+        else:
+            self.emb = nn.Sequential(nn.Embedding(max_x + 1, channels_1wl), GraphNorm(channels_1wl),
+                                     nn.Dropout(p=dp_emb, inplace=True))
         self.conv1s = nn.ModuleList([relu_conv(channels_1wl, channels_1wl, dp_1wl0, act0) for _ in range(depth1 - 1)]
                                     + [relu_conv(channels_1wl, channels_2wl, dp_1wl1, act1)])
         self.conv2s = nn.ModuleList([relu_conv(channels_2wl, channels_2wl, dp_2wl, True) for _ in range(depth2)])
@@ -151,8 +156,8 @@ class LocalWLNet(nn.Module):
         edge2 = graph_cache.get(ei2, None, P, True, flip=1)
         edge2_r = graph_cache.get(ei2, None, P, True, flip=2)
         if self._small_graph_ok(x, edge1, P):
-            if idx is None or ei2 is None or torch.cuda.is_current_stream_capturing():
-                return self._forward_small(x, edge1, pos, idx, edge2, edge2_r)
+            if idx is None or ei2 is None or self.use_node_feat or torch.cuda.is_current_stream_capturing():
+                return self._forward_small(x, edge1, pos, idx, edge2, edge2_r)      # (the block format has no linear / LayerNorm launch)
             # first forward over these inputs: run the launches one by one, recording them (and checking the indices:
             # the recorded block is only replayed for the same tensors at the same versions, so once is enough)
             self._plan_params = [p for p in self.parameters()]
@@ -163,8 +168,7 @@ class LocalWLNet(nn.Module):
             self._plan = _SmallPlan(key, rec["words"], rec["keep"] + [x, edge1, pos, idx, ei2, edge2, edge2_r],
                                     tuple(out.shape), out.device)
             return out
-        x = _ops.embedding(self.emb[0].weight, x)                      # Embedding(deg)
-        x = self.emb[1](x)                                             # GraphNorm (Dropout: eval identity)
+        x = self._input_features(x)
         for conv1 in self.conv1s:
             x = conv1(x, edge1)                                        # K5 + K3/K4 + K6
         x = _ops.pair_gather_mul(x, pos)                               # K7
@@ -174,12 +178,22 @@ class LocalWLNet(nn.Module):
         _ops.maybe_check(out.device, "LocalWLNet index")
         return out
 
+    def _input_features(self, x):
+        """model.py:71: lin1(node_feat) (Linear + bias on the matrix cores, then the row-wise LayerNorm; the dropouts
+        are eval-mode identities) or GraphNorm(Embedding(x))"""
+        if self.use_node_feat:
+            lin, ln = self.lin1[1][0], self.lin1[1][1]
+            return _ops.layer_norm_rows(_ops.linear(self.node_feat, lin.weight, lin.bias), ln.eps)
+        return self.emb[1](_ops.embedding(self.emb[0].weight, x))
+
     def _small_graph_ok(self, x, edge1, P):
-        if not (_SMALL_PATH and x.is_cuda and not isinstance(edge1, _ops.CSRGraph)):
+        if not (_SMALL_PATH and (self.node_feat if self.use_node_feat else x).is_cuda and not isinstance(edge1, _ops.CSRGraph)):
             return False
         cap = _ops.small_max_rows()
         convs = list(self.conv1s) + list(self.conv2s) + list(self.conv2s_r)
-        return (0 < x.shape[0] <= cap and 0 < P <= cap and self.emb[0].weight.shape[1] % 4 == 0
+        n = self.node_feat.shape[0] if self.use_node_feat else x.shape[0]
+        c1 = self.conv1s[0].modlist[0].in_channels
+        return (0 < n <= cap and 0 < P <= cap and c1 % 4 == 0
                 and len(self.conv2s) == len(self.conv2s_r) >= 1
                 and all(_is_relu_conv(s) and s.modlist[0].in_channels <= 256 for s in convs)
                 and len({s.modlist[1].eps for s in convs}) == 1)
@@ -191,10 +205,13 @@ class LocalWLNet(nn.Module):
         the result next, embedding + GraphNorm in one launch, the pair product folded into the first 2-WL linear,
         both orientations of a 2-WL layer in the same two launches, their sum folded into the next linear / the
         readout.  21 launches -> 6 at depth 1/1."""
-        N, P = x.shape[0], pos.shape[0]
+        N, P = (self.node_feat.shape[0] if self.use_node_feat else x.shape[0]), pos.shape[0]
         g1 = graph_cache.get(edge1, None, N, True)
-        norm0 = self.emb[1]
-        h = _ops.embedding_graph_norm(self.emb[0].weight, x, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps)
+        if self.use_node_feat:
+            h = self._input_features(x)
+        else:
+            norm0 = self.emb[1]
+            h = _ops.embedding_graph_norm(self.emb[0].weight, x, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps)
         for seq in self.conv1s:
             hT = _ops.small_linear_t(h, seq.modlist[0].lin.weight)
             h, = _ops.small_gcn(N, [_side(hT, g1, seq)])
@@ -240,9 +257,14 @@ class LocalWLNet(nn.Module):
         """plain-numpy parameter dict in the layout oracle.aggregation.localwl_forward reads."""
         p = {"depth1": len(self.conv1s), "depth2": len(self.conv2s)}
         t = lambda v: v.detach().cpu().double().numpy()
-        p["emb.weight"] = t(self.emb[0].weight)
-        for k in ("weight", "bias", "mean_scale"):
-            p[f"emb_norm.{k}"] = t(getattr(self.emb[1], k))
+        if self.use_node_feat:
+            p["node_feat"] = t(self.node_feat)
+            p["lin1.weight"], p["lin1.bias"] = t(self.lin1[1][0].weight), t(self.lin1[1][0].bias)
+            p["lin1.eps"] = float(self.lin1[1][1].eps)
+        else:
+            p["emb.weight"] = t(self.emb[0].weight)
+            for k in ("weight", "bias", "mean_scale"):
+                p[f"emb_norm.{k}"] = t(getattr(self.emb[1], k))
         for name in ("conv1s", "conv2s", "conv2s_r"):
             for l, seq in enumerate(getattr(self, name)):
                 conv, norm, act = seq.modlist[0], seq.modlist[1], seq.modlist[3]

@@ -118,6 +118,23 @@ def graph_norm(x, weight, bias, mean_scale, eps=1e-5):
     return np.asarray(weight, dtype=np.float64)[None, :] * o / np.sqrt(var + eps) + np.asarray(bias, dtype=np.float64)[None, :]
 
 
+def layer_norm(x, eps=1e-5):
+    """torch.nn.LayerNorm(d, elementwise_affine=False) (TwoWL/model/model.py:30): per row, biased variance."""
+    x = np.asarray(x, dtype=np.float64)
+    mu = x.mean(axis=1, keepdims=True)
+    return (x - mu) / np.sqrt(((x - mu) ** 2).mean(axis=1, keepdims=True) + eps)
+
+
+def input_features(p, x_deg):
+    """TwoWL/model/model.py:71 -- lin1(node_feat) (Dropout -> Linear -> LayerNorm -> Dropout, eval: :28-33,47-51) when
+    the model was built with use_node_feat, else GraphNorm(Embedding(x)) (:53-55)."""
+    if "lin1.weight" in p:
+        h = np.asarray(p["node_feat"], dtype=np.float64) @ np.asarray(p["lin1.weight"], dtype=np.float64).T
+        return layer_norm(h + np.asarray(p["lin1.bias"], dtype=np.float64)[None, :], p.get("lin1.eps", 1e-5))
+    x = np.asarray(p["emb.weight"], dtype=np.float64)[np.asarray(x_deg, dtype=np.int64)]
+    return graph_norm(x, p["emb_norm.weight"], p["emb_norm.bias"], p["emb_norm.mean_scale"])
+
+
 # ----------------------------------------------------------------------------- TwoWL forward
 def pair_hadamard(x, pos):
     """TwoWL/model/model.py:75 -- h[t] = x[pos[t,0]] * x[pos[t,1]]."""
@@ -139,8 +156,7 @@ def localwl_forward(params, x_deg, edge1, pos, idx, ei2):
     from .twowl_int import reverse
     edge2, edge2_r = reverse(ei2)
     p = params
-    x = np.asarray(p["emb.weight"], dtype=np.float64)[np.asarray(x_deg, dtype=np.int64)]
-    x = graph_norm(x, p["emb_norm.weight"], p["emb_norm.bias"], p["emb_norm.mean_scale"])
+    x = input_features(p, x_deg)
     for l in range(p["depth1"]):
         x = gcn_conv(x, edge1, p[f"conv1s.{l}.lin.weight"], p[f"conv1s.{l}.bias"])
         x = graph_norm(x, p[f"conv1s.{l}.norm.weight"], p[f"conv1s.{l}.norm.bias"], p[f"conv1s.{l}.norm.mean_scale"])

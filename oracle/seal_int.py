@@ -9,15 +9,18 @@ Pure Python / numpy, no networkx: BFS on the dense 0/1 adjacency.
 import numpy as np
 
 
-def build_train_adjacency(positive, n_nodes, test_ratio=0.1):
+def build_train_adjacency(positive, n_nodes, test_ratio=0.1, network_type=0):
     """SEAL/config/subgraph.py:23-31 -- only the first len(positive)-test_size positives enter
-    A (undirected: both orientations set; self loops sit on the diagonal)."""
+    A (undirected: both orientations set; network_type = 1: the stored orientation only; self loops sit on the
+    diagonal).  Everything below reads ROWS of A (successors), as nx.neighbors / nx.DiGraph(data=adj) do, so the
+    same functions restate the directed case."""
     positive = np.asarray(positive, dtype=np.int64)
     test_size = int(len(positive) * test_ratio)
     train_pos = positive[:-test_size]
     A = np.zeros((n_nodes, n_nodes), dtype=np.uint8)
     A[train_pos[:, 0], train_pos[:, 1]] = 1
-    A[train_pos[:, 1], train_pos[:, 0]] = 1
+    if network_type == 0:
+        A[train_pos[:, 1], train_pos[:, 0]] = 1
     return A
 
 

@@ -157,6 +157,70 @@ def gen_seal():
     np.savez_compressed(os.path.join(HERE, "seal_int.npz"), **out)
 
 
+def gen_seal_directed():
+    """seal_dir.npz: the same reference functions with network_type = 1 (nx.DiGraph; A set in one orientation only,
+    SEAL/config/subgraph.py:29-31,69; directed shortest paths in node_labeling, SEAL/utils/utils.py:38) on
+    fb-pages-food read as a DIRECTED edge list, hop 1, plus node_labeling known answers on random directed graphs."""
+    import networkx as nx
+
+    class _G(nx.Graph):
+        def __init__(self, incoming_graph_data=None, data=None, **attr):
+            super().__init__(data if data is not None else incoming_graph_data, **attr)
+
+    class _DG(nx.DiGraph):
+        def __init__(self, incoming_graph_data=None, data=None, **attr):
+            super().__init__(data if data is not None else incoming_graph_data, **attr)
+
+    nx.Graph, nx.DiGraph = _G, _DG
+    sys.path.insert(0, REF)
+    from SEAL.config import subgraph as ref_sub
+    from SEAL.utils import utils as ref_utils
+    import pandas as pd
+
+    # candidate pairs as SEAL/config/data.py:17-27 makes them for network_type = 1 (header row eaten, DiGraph non-edges)
+    np.random.seed(0)
+    positive = pd.read_csv(os.path.join(HERE, "fb-pages-food.edges"), delimiter=",", dtype=int).to_numpy()
+    G = nx.DiGraph()
+    G.add_edges_from(positive)
+    negative_all = sorted(nx.non_edges(G))          # sorted: independent of iteration order
+    np.random.shuffle(negative_all)
+    negative = np.asarray(negative_all[:len(positive)])
+    np.random.shuffle(positive)
+    n_nodes = len(G.nodes())
+    out = {"positive": positive.astype(np.int32), "negative": negative.astype(np.int32), "n_nodes": np.int64(n_nodes)}
+    np.random.seed(2)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        graphs_adj, labels, vertex_tags, node_size_list, sub_nodes, tags_size = \
+            ref_sub.link2subgraph(positive.copy(), negative.copy(), n_nodes, 0.1, 1, 1, 100)
+    n = np.asarray(node_size_list, dtype=np.int32)
+    out["hop1_n"] = n
+    out["hop1_off"] = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    out["hop1_nodes"] = np.concatenate([np.asarray(s, dtype=np.int32) for s in sub_nodes])     # reference order
+    out["hop1_tags"] = np.concatenate([np.asarray(t, dtype=np.int32) for t in vertex_tags])    # after compaction
+    out["hop1_tags_size"] = np.int64(tags_size)
+    out["hop1_nnz"] = np.asarray([int(np.asarray(a).sum()) for a in graphs_adj], dtype=np.int32)
+    crc = []
+    for a, s in zip(graphs_adj, sub_nodes):
+        pm = canon_perm(s)
+        crc.append(zlib.crc32(pack_adj(np.asarray(a)[pm][:, pm]).tobytes()))
+    out["hop1_adj_crc_canon"] = np.asarray(crc, dtype=np.uint32)
+    out["hop1_labels"] = np.asarray(labels, dtype=np.uint8).reshape(-1)
+    print(f"[seal directed] hop=1: {len(n)} subgraphs, tags_size={tags_size}, n min/med/mean/max = "
+          f"{n.min()}/{int(np.median(n))}/{n.mean():.1f}/{n.max()}, asymmetric subgraphs: "
+          f"{sum(int((np.asarray(a) != np.asarray(a).T).any()) for a in graphs_adj)}")
+    rng = np.random.RandomState(11)
+    kat_n, kat_adj, kat_tags = [], [], []
+    for _ in range(200):
+        nn = int(rng.randint(2, 41))
+        a = (rng.rand(nn, nn) < rng.choice([0.05, 0.1, 0.2, 0.5])).astype(np.uint8)
+        a[0, 1] = a[1, 0] = 0
+        kat_n.append(nn); kat_adj.append(pack_adj(a)); kat_tags.append(ref_utils.node_labeling(a, 1))
+    out["kat_n"] = np.asarray(kat_n, dtype=np.int32)
+    out["kat_adj_bits"] = np.concatenate(kat_adj)
+    out["kat_tags"] = np.concatenate([np.asarray(t, dtype=np.int32) for t in kat_tags])
+    np.savez_compressed(os.path.join(HERE, "seal_dir.npz"), **out)
+
+
 def gen_twowl():
     import types
     import torch
@@ -245,7 +309,9 @@ def gen_seal_weights():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["seal", "twowl", "weights"]
+    which = sys.argv[1:] or ["seal", "seal_dir", "twowl", "weights"]
+    if "seal_dir" in which:
+        gen_seal_directed()
     if "weights" in which:
         gen_seal_weights()
     if "twowl" in which:

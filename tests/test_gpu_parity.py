@@ -611,6 +611,38 @@ def test_localwl_forward_fb_pages_food(dev, tw, c1, c2, d1, d2):
               f"{np.abs(got - want).max():.2e} = {np.abs(got - want).max() / scale:.1e} of the logit scale {scale:.1f}")
 
 
+@pytest.mark.parametrize("small", [True, False])
+def test_localwl_node_feature_branch(dev, tw, monkeypatch, small):
+    """LocalWLNet(use_node_feat=True) (TwoWL/model/model.py:47-51: Dropout -> Linear -> LayerNorm(no affine) -> Dropout
+    in place of the degree embedding): the row-wise LayerNorm kernel against the fp64 definition at 1e-5 of what it
+    sums, the whole forward at 1e-5 of the logit scale on both device paths, state_dict keys as the reference's."""
+    from lpgnn_amd import ops, twowl
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(17)
+    for n, d in [(620, 256), (7, 1), (1000, 100), (33, 1024)]:
+        x = (rng.standard_normal((n, d)) * rng.uniform(0.1, 5.0, size=(n, 1)) + rng.uniform(-2, 2, size=(n, 1))).astype(np.float32)
+        got = _np(ops.layer_norm_rows(torch.from_numpy(x).to(dev)))
+        x64 = x.astype(np.float64)
+        want = agg.layer_norm(x64)
+        s_ = np.sqrt(x64.var(axis=1, keepdims=True) + 1e-5)
+        mag = (np.abs(x64) + np.abs(x64.mean(axis=1, keepdims=True))) / s_        # what (x - mean) / s sums
+        assert np.all(np.abs(got - want) <= TOL * mag + 1e-30)
+    ei, pred, ei2 = tw["test_ei"].astype(np.int64), tw["test_pred"].astype(np.int64), tw["test_ei2"].astype(np.int64)
+    pos1 = np.concatenate([ei.T, pred.T], axis=0)
+    feat = torch.from_numpy(rng.standard_normal((620, 40)).astype(np.float32)).to(dev)
+    torch.manual_seed(4)
+    mod = twowl.LocalWLNet(0, use_node_feat=True, node_feat=feat, channels_1wl=64, channels_2wl=24, depth1=2, depth2=1).to(dev).eval()
+    assert {"lin1.1.0.weight", "lin1.1.0.bias"} <= set(mod.state_dict()) and not any(k.startswith("emb") for k in mod.state_dict())
+    t = lambda a: torch.from_numpy(a).to(dev)
+    monkeypatch.setattr(twowl, "_SMALL_PATH", small)
+    y_len = pred.shape[1]
+    x_dummy = torch.zeros(620, dtype=torch.int64, device=dev)
+    logits = twowl.test_forward(mod, x_dummy, t(ei), t(pos1), y_len, t(ei2))
+    idx = ei.shape[1] + np.arange(y_len)
+    want = agg.localwl_forward(mod.export_params(), None, ei, pos1, idx, ei2)
+    assert np.abs(_np(logits) - want).max() <= TOL * np.abs(want).max()
+
+
 # ------------------------------------------------------------------ small-graph GCN blocks (the launch-bound regime)
 def test_localwl_small_path_matches_generic_path(dev, tw, monkeypatch):
     """the two-launches-per-block path (default for <= 8192 rows) and the kernel-per-op path on the fb-pages-food
@@ -841,22 +873,27 @@ def _unpack_adj(bits_row_words, n):
     return a
 
 
-@pytest.mark.parametrize("hop", [1, 0])
-def test_seal_subgraphs_golden(dev, sl, hop):
+@pytest.mark.parametrize("hop,directed", [(1, False), (0, False), (1, True)])
+def test_seal_subgraphs_golden(dev, sl, golden_dir, hop, directed):
     """all 4202 fb-pages-food candidates: node set, canonical adjacency and DRNL tags bit-exact;
-    pairs where the reference's RNG truncation fires are replayed in the reference's node order."""
+    pairs where the reference's RNG truncation fires are replayed in the reference's node order.  directed: the
+    reference's own run with network_type = 1 (nx.DiGraph, A in one orientation, directed shortest paths)."""
     from lpgnn_amd import seal
+    from oracle import seal_int
+    if directed:
+        sl = np.load(os.path.join(golden_dir, "seal_dir.npz"))
     pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
     k = f"hop{hop}_"
     off, nodes_ref, tags_ref = sl[k + "off"], sl[k + "nodes"], sl[k + "tags"]
-    graph = seal.build_train_csr(pos, 620, 0.1, dev)
+    graph = seal.build_train_csr(pos, 620, 0.1, dev, network_type=int(directed))
+    assert graph.directed == directed
     pairs = np.concatenate([neg, pos])
     batch = seal.extract_subgraphs(pairs, graph, hop, cap_policy="report")
     n, capped = _np(batch.n), _np(batch.capped).astype(bool)
     nodes, tags, bits = _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits)
     ref_n = np.diff(off)
     assert np.array_equal(n[~capped], ref_n[~capped])
-    if hop == 1:
+    if hop == 1 and not directed:
         assert capped.sum() > 0
     # replay the capped ones in the reference's own node order
     ci = np.nonzero(capped)[0]
@@ -874,9 +911,14 @@ def test_seal_subgraphs_golden(dev, sl, hop):
             raw.append((nodes_ref[off[g]:off[g + 1]], r_tags[q, : ref_n[g]], r_bits[q]))
         else:
             raw.append((nodes[g, : n[g]], tags[g, : n[g]], bits[g]))
-    uniq = sorted(set(int(t) for _, tg, _ in raw for t in tg))
-    assert len(uniq) == int(sl[k + "tags_size"])
-    tmap = {t: i for i, t in enumerate(uniq)}
+    # ... in the reference's order: position in list(set of all tags), CPython set iteration order (ascending for the
+    # undirected run's small tags; the directed run reaches tags >= 8, where hash collisions can reorder the set)
+    order = seal._cpython_set_order(tg for _, tg, _ in raw)
+    assert len(order) == int(sl[k + "tags_size"])
+    tmap = {t: i for i, t in enumerate(order)} if set(order) != set(range(len(order))) else {t: t for t in order}
+    if not capped.any():                                 # the product's own map of the same batch (no replayed pairs)
+        tm, T = seal.compact_tag_map(batch)
+        assert T == len(order) and all(int(_np(tm)[t]) == tmap[t] for t in order)
     for g in range(len(pairs)):
         nd, tg, bb = raw[g]
         ref_nd = nodes_ref[off[g]:off[g + 1]]

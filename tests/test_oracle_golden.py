@@ -62,11 +62,31 @@ def test_node_labeling_known_answers(sl):
     assert list(tags[:5]) == [1, 1, 2, 4, 9]      # SURVEY section 8c known answer
 
 
-@pytest.mark.parametrize("hop", [1, 0])
-def test_enclosing_subgraphs_all_pairs(sl, hop):
-    """all 4202 candidate pairs: node set, canonical adjacency (crc) and tags, bit-exact."""
+@pytest.fixture(scope="module")
+def sd(golden_dir):
+    return np.load(os.path.join(golden_dir, "seal_dir.npz"))
+
+
+def test_node_labeling_known_answers_directed(sd):
+    """SEAL/utils/utils.py:35-54 with network_type = 1 (nx.DiGraph): 200 random directed graphs, tags from the reference"""
+    n, bits, tags = sd["kat_n"], sd["kat_adj_bits"], sd["kat_tags"]
+    bo = to = 0
+    for nn in n:
+        nb = (nn * nn + 7) // 8
+        adj = np.unpackbits(bits[bo:bo + nb])[: nn * nn].reshape(nn, nn)
+        assert list(seal_int.node_labeling(adj)) == list(tags[to:to + nn])
+        bo += nb
+        to += nn
+
+
+@pytest.mark.parametrize("hop,directed", [(1, False), (0, False), (1, True)])
+def test_enclosing_subgraphs_all_pairs(sl, sd, hop, directed):
+    """all 4202 candidate pairs: node set, canonical adjacency (crc) and tags, bit-exact -- undirected (hop 1, 0) and
+    the reference run with network_type = 1 (fb-pages-food read as a directed edge list, hop 1)."""
+    sl = sd if directed else sl
     pos, neg = sl["positive"], sl["negative"]
-    A = seal_int.build_train_adjacency(pos, int(sl["n_nodes"]))
+    A = seal_int.build_train_adjacency(pos, int(sl["n_nodes"]), network_type=int(directed))
+    assert bool((A != A.T).any()) == directed
     k = f"hop{hop}_"
     off, nodes_ref, tags_ref = sl[k + "off"], sl[k + "nodes"], sl[k + "tags"]
     pairs = np.concatenate([neg, pos])            # link2subgraph: negatives first (:74)
