@@ -447,6 +447,27 @@ int lpg_seal_sortpool_f32(const float* z, int64_t ldz, const float* key, const i
                           int64_t B, int64_t k, int64_t C, float* out, void* stream);
 int lpg_softmax2_pos_score_f32(const float* pre_y, int64_t B, float* score, void* stream);
 
+/* ---------------------------------------------------------------- RCCL: sum of the per-rank partial aggregates
+ * The north star's "RCCL all-reduce of partial node aggregates over xGMI" at the C boundary (build-defined: the
+ * reference has no distributed code).  One process per GPU.  librccl is resolved with dlopen("librccl.so.1") at first
+ * use -- inside a PyTorch process that is the copy torch already loaded -- so the library has no link-time dependency
+ * on it; lpg_comm_available() = 1 when it resolved.  id128: HOST memory, 128 bytes (ncclUniqueId): rank 0 creates it,
+ * the caller ships it to the other ranks by any host channel, every rank calls lpg_comm_init with the device it owns
+ * current; *comm (HOST pointer to a handle) is an ncclComm_t.  Collectives enqueue on `stream` and return; buffers
+ * are device memory, fp32 or (is_bf16 != 0) bf16; `send` may equal `recv` for the all-reduce.
+ * lpg_reduce_scatter_sum: send holds world * recv_count elements, rank r keeps the sum of every rank's r-th block --
+ * the shard the next layer on the same source partition reads (half the all-reduce's bytes per link).
+ * Returns LPG_E_UNSUPPORTED when RCCL cannot be loaded, LPG_E_LAUNCH with RCCL's message on a collective error.
+ * The host mirror (lpgnn_amd.dist) drives the same collectives through torch.distributed, whose "nccl" backend IS
+ * RCCL; RcclComm there wraps these entry points for callers without torch.distributed. */
+int lpg_comm_available(void);
+int lpg_comm_unique_id(void* id128);
+int lpg_comm_init(void** comm, int world, int rank, const void* id128);
+int lpg_comm_destroy(void* comm);
+int lpg_allreduce_sum(void* comm, const void* send, void* recv, int64_t count, int is_bf16, void* stream);
+int lpg_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t recv_count, int is_bf16,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

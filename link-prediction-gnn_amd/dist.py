@@ -379,3 +379,59 @@ class ShardedLinkScorer:
             a, b = source_range(B, self.world, r)
             parts.append(recv[r * width: r * width + (b - a)])
         return torch.cat(parts)
+
+
+class RcclComm:
+    """RCCL through the library's own C entry points (include/lpg_hip.h: lpg_comm_*, lpg_allreduce_sum,
+    lpg_reduce_scatter_sum) -- the C boundary a non-PyTorch host would bind.  The 128-byte unique id travels through
+    `exchange(id_bytes_or_None) -> id_bytes` (rank 0 passes its id, every rank gets rank 0's back): by default a
+    torch.distributed broadcast_object_list on the already-initialised process group (any backend, e.g. gloo)."""
+
+    def __init__(self, world, rank, exchange=None):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        lib = _lib.load()
+        if not lib.lpg_comm_available():
+            raise _lib.LpgError("RCCL is not available in this process (dlopen(librccl.so.1) failed)")
+        idb = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.lpg_comm_unique_id(ctypes.addressof(idb)), "comm_unique_id")
+        if exchange is None:
+            import torch.distributed as dist
+
+            def exchange(b):
+                box = [b]
+                if world > 1:
+                    dist.broadcast_object_list(box, src=0)
+                return box[0]
+        got = exchange(idb.raw if rank == 0 else None)
+        idb = ctypes.create_string_buffer(got, 128)
+        self._comm = ctypes.c_void_p()
+        _lib.check(lib.lpg_comm_init(ctypes.addressof(self._comm), int(world), int(rank), ctypes.addressof(idb)), "comm_init")
+        self.world, self.rank = int(world), int(rank)
+
+    def _args(self, t):
+        if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("RcclComm: contiguous float32 / bfloat16 device tensors")
+        return int(t.dtype == torch.bfloat16), torch.cuda.current_stream(t.device).cuda_stream
+
+    def all_reduce_(self, t):
+        """t <- sum over ranks (in place), enqueued on the current stream"""
+        bf, st = self._args(t)
+        self._lib.check(self._lib.load().lpg_allreduce_sum(self._comm, t.data_ptr(), t.data_ptr(), t.numel(), bf, st), "allreduce_sum")
+        return t
+
+    def reduce_scatter(self, send, out=None):
+        """send [world * k, ...] -> this rank's block of the sum, [k, ...]"""
+        bf, st = self._args(send)
+        k = send.shape[0] // self.world
+        out = out if out is not None else torch.empty((k,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        self._lib.check(self._lib.load().lpg_reduce_scatter_sum(self._comm, send.data_ptr(), out.data_ptr(), out.numel(), bf, st),
+                        "reduce_scatter_sum")
+        return out
+
+    def close(self):
+        if self._comm:
+            self._lib.check(self._lib.load().lpg_comm_destroy(self._comm), "comm_destroy")
+            self._comm = self._ct.c_void_p()

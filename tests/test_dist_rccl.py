@@ -57,6 +57,17 @@ def _rccl_worker(rank, world, port, q):
     def score_fn(p):                                      # stands in for the single-GPU SEAL scorer
         return (p[:, 0] * 1000 + p[:, 1]).to(torch.float32)
 
+    # the library's own RCCL entry points (lpg_comm_init / lpg_allreduce_sum / lpg_reduce_scatter_sum), id over the store
+    comm = ldist.RcclComm(world, rank)
+    v = torch.arange(4096, dtype=torch.float32, device=dev) * (rank + 1)
+    want = torch.arange(4096, dtype=torch.float32, device=dev) * (world * (world + 1) / 2)
+    out["c_allreduce"] = bool(torch.equal(comm.all_reduce_(v.clone()), want))
+    out["c_allreduce_bf16"] = bool(torch.equal(comm.all_reduce_(torch.ones(257, device=dev).bfloat16()),
+                                               torch.full((257,), float(world), device=dev).bfloat16()))
+    blk = comm.reduce_scatter(v.view(world, -1).contiguous().view(world * (4096 // world), 1))
+    out["c_reduce_scatter"] = bool(torch.equal(blk.view(-1), want.view(world, -1)[rank]))
+    torch.cuda.synchronize()
+    comm.close()
     pairs = torch.arange(2 * 1001, dtype=torch.int64, device=dev).view(1001, 2)
     sc = ldist.ShardedLinkScorer(score_fn, always_collective=True)             # the all_gather_into_tensor branch
     out["scores"] = bool(torch.equal(sc(pairs, gather=True), score_fn(pairs)))
@@ -80,6 +91,7 @@ def _run(world):
     for rank in range(world):
         out = res[rank]
         assert out["backend"] == "nccl" and out["scores"]
+        assert out["c_allreduce"] and out["c_allreduce_bf16"] and out["c_reduce_scatter"]
         for collective in ("reduce_scatter", "all_reduce", "sparse"):
             err, scale, used, packed, _ = out[collective]
             assert used == collective and packed == (collective == "sparse")
