@@ -37,7 +37,9 @@ constexpr int RMAX = WIN + MAXN;      // rows it can end up with (<= 255)
 constexpr int kConvBlock = 256;       // 4 waves, up to two 32-row tiles each
 constexpr int HS = 256 + 8;           // row stride of a transposed bf16 plane (528 B: 16-byte aligned; 132 dwords = 4 mod 16)
 
-__device__ __forceinline__ float tanh_fast_div(float v) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f); }
+// tanh(v) = 1 - 2 / (exp(2 v) + 1): v_exp_f32 and v_rcp_f32 (1 ulp each; __frcp_rn expands to the ten-instruction IEEE division
+// sequence, 16 times per tile and layer): |error| < 4e-7 absolute on an output in [-1, 1]; saturates cleanly
+__device__ __forceinline__ float tanh_fast_div(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }

@@ -4,6 +4,9 @@ settings of the existing kernel -- is a cache-resident gather faster with more w
 import json
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _opts                # LPG_* variables -> the library's option table (profiles/_opts.py)
+import sys
 
 import torch
 
@@ -42,7 +45,8 @@ for H in (8192, 32768):
         res = {"H": H, "part": name, "edges": sub.shape[1]}
         for lds in ("0", "40000", "65536", "90000"):
             os.environ["LPG_SPMM_LDS"] = lds
+            _opts.sync()
             res["lds" + lds] = round(t(g), 3)
-        os.environ.pop("LPG_SPMM_LDS")
+        os.environ.pop("LPG_SPMM_LDS"); _opts.sync()
         print(json.dumps(res), flush=True)
         del g

@@ -3,6 +3,9 @@
 W-resident kernels (linear_wres.hip), same process, interleaved; each checked against an fp64 matmul."""
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _opts                # LPG_* variables -> the library's option table (profiles/_opts.py)
+import sys
 
 import torch
 
@@ -57,6 +60,7 @@ for n, k, m, ldx, km, dt, acti, has_b in shapes:
     res = {}
     for mode in ("0", "1", "2", "3"):
         os.environ["LPG_LINEAR_WRES"] = mode
+        _opts.sync()
         y = ops.linear(x, w, b, w_is_km=km, act=act)
         res[mode] = y
         out[mode] = timed(lambda: ops.linear(x, w, b, w_is_km=km, act=act))

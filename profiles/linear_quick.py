@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """quick timing of the dense linear at the headline shapes (fp32 / bf16, n = 5 M)."""
 import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _opts                # LPG_* variables -> the library's option table (profiles/_opts.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lpgnn_amd import ops
@@ -21,9 +23,10 @@ for dt in (torch.float32, torch.bfloat16):
         for mode in sys.argv[1:] or ["auto"]:
             if mode == "auto": os.environ.pop("LPG_LINEAR_WRES", None)
             else: os.environ["LPG_LINEAR_WRES"] = mode
+            _opts.sync()
             r.append(f"{mode}={timed(lambda: ops.linear(x, w)):.3f}")
         ref = x[:4096].double() @ w.double().t()
-        os.environ["LPG_LINEAR_WRES"] = "3"
+        os.environ["LPG_LINEAR_WRES"] = "3"; _opts.sync()
         err = float(((ops.linear(x, w)[:4096].double() - ref).abs() / (1 + ref.abs())).max())
         print(str(dt)[6:], k, m, " ".join(r), "ms  v3 err", f"{err:.1e}", flush=True)
         del x, w

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """SpMM on the block-diagonal SEAL batch graph (1.46 M rows, 8.5 M nnz, weighted, tanh epilogue) vs d and chunk."""
 import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _opts                # LPG_* variables -> the library's option table (profiles/_opts.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
@@ -21,6 +23,7 @@ def T(fn, it=20):
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / it * 1e3
 for chunk in sys.argv[1:] or ["0"]:
     os.environ["LPG_SPMM_CHUNK"] = chunk
+    _opts.sync()
     g, d_inv, x = seal.gnn_inputs(batch, tag_map, Tn, None)
     out = []
     for d in (1, 2, 4, 8, 16, 32, 64):

@@ -2,6 +2,8 @@
 """One pipeline stage of the source-partitioned SpMM as rank 0 of 8 sees it: X shard 625 K rows (320 MB),
 25 M edges into 1.25 M destination rows (a quarter of V), d = 128 fp32 -- occupancy limiter on / off."""
 import os, sys, statistics, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _opts                # LPG_* variables -> the library's option table (profiles/_opts.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench, lpgnn_amd
@@ -14,6 +16,7 @@ g = lpgnn_amd.CSRGraph.from_edge_index(ei, V // S, V // G)
 x = torch.randn((V // G, d), device=dev)
 for lds in ("-1", "0", "65536", "90000"):
     os.environ["LPG_SPMM_LDS"] = lds
+    _opts.sync()
     ts = []
     for _ in range(4):
         g.spmm(x); torch.cuda.synchronize()

@@ -5,6 +5,10 @@ over several rounds on the same graph / same allocation (device-to-device and ru
     python profiles/sweep_spmm.py [K=V,K=V ...]      (each argument is one variant)"""
 import json
 import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _opts                # LPG_* variables -> the library's option table (profiles/_opts.py)
+_opts.use_tuning_build()    # MODE 2 (gather-only) exists in the -DLPG_TUNING build only
 import statistics
 import sys
 
@@ -29,6 +33,7 @@ for rnd in range(ROUNDS):
         for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update({("LPG_SPMM_" + k if not k.startswith("LPG_") else k): val for k, val in v.items() if val != ""})
+        _opts.sync()
         g._build_plan()                      # the plan depends on the chunk size
         for _ in range(2):
             g.spmm(x)
