@@ -18,7 +18,7 @@ using namespace lpg;
 constexpr int MAXN = LPG_SEAL_MAXN;  // 128 >= the reference's max_neighbors = 100
 constexpr int WORDS = MAXN / 32;
 constexpr int kSealBlock = 128;      // thread i <-> subgraph vertex i
-constexpr int kDeferGroup = 8;       // consecutive pairs a 128-thread workgroup owns in the fused launch (it handles those no wave can)
+constexpr int kDeferGroup = 8;       // consecutive pairs a 128-thread workgroup owns in the fused launch on big batches (it handles those no wave can)
 __device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ bool row_has(const int32_t* __restrict__ row, int len, int32_t key) {
@@ -323,6 +323,7 @@ struct BigPairLds {
   int big[MAXN];                        // rows whose list is searched instead of streamed
   int pre[MAXN + 2];                    // exclusive prefix of the streamed rows' list lengths
   uint32_t member[128];                 // 4096-bit hash filter of the subgraph's vertices (no false negatives)
+  int hidx[MAXN];                       // hub-matrix row of each big row's node (-1: none)
 };
 
 // latency-bound: 8 waves per SIMD (64 VGPRs, 6 of them spilled) beat 6 waves with none
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag,
     uint8_t* __restrict__ tag_present, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
     int hub_words, int fused, int directed) {
+  const int group = fused > 0 ? fused : 1;           // fused = consecutive pairs per team workgroup (0: not fused)
   // directed != 0 (SEAL/config/subgraph.py:30-31,69 with network_type = 1): the CSR lists SUCCESSORS only and the induced
   // adjacency is not symmetric -- no entry is mirrored, and rows that are not streamed are searched against every column.
   // fused == 0: workgroup w takes pairs w, w + gridDim.x, ... with all 128 threads (every pair; replayed node lists).
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
   } lds;
   WavePair* const wp = lds.wave;
   __shared__ uint8_t s_defer[kDeferGroup];
-  const int64_t n_groups = fused ? ceil_div_dev(B, kDeferGroup) : 0;
+  const int64_t n_groups = fused ? ceil_div_dev(B, group) : 0;
   if (fused && static_cast<int64_t>(blockIdx.x) >= n_groups) {
     const int64_t bw = (static_cast<int64_t>(blockIdx.x) - n_groups) * (kSealBlock / 64) + (threadIdx.x >> 6);
     if (bw < B)                                          // wave-uniform; wave_pair has no workgroup barrier
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
   int (&big)[MAXN] = lds.team.big;
   int (&pre)[MAXN + 2] = lds.team.pre;
   uint32_t (&member)[128] = lds.team.member;
+  int (&hidx)[MAXN] = lds.team.hidx;
   const int t = threadIdx.x;
 
   for (int64_t iter = 0;; ++iter) {
@@ -383,8 +386,8 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     int64_t b;
     if (fused) {
       if (iter == 0) {                                   // who owns my kDeferGroup pairs: one thread per pair, in parallel
-        if (t < kDeferGroup) {
-          const int64_t bq = static_cast<int64_t>(blockIdx.x) * kDeferGroup + t;
+        if (t < group) {
+          const int64_t bq = static_cast<int64_t>(blockIdx.x) * group + t;
           bool mine = false;
           if (bq < B) {
             const int64_t uq = pairs[2 * bq], vq = pairs[2 * bq + 1];
@@ -396,8 +399,8 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
         }
         __syncthreads();
       }
-      if (iter >= kDeferGroup) break;
-      b = static_cast<int64_t>(blockIdx.x) * kDeferGroup + iter;
+      if (iter >= group) break;
+      b = static_cast<int64_t>(blockIdx.x) * group + iter;
       if (b >= B) break;
       if (!s_defer[iter]) continue;                      // block-uniform
     } else {
@@ -642,17 +645,35 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     bool search = true;
     if (hub_index && !allcols) {
       if (t == 0) s_search = 0;
+      if (t < nbig) hidx[t] = hub_index[nodes[big[t]]];           // one load per big row, all in flight together
       __syncthreads();
-      for (int p = t; p < nbig * nbig; p += kSealBlock) {
-        const int a = p / nbig, b2 = p - a * nbig;
-        if (a > b2) continue;
-        const int i = big[a], j = big[b2];
-        const int ia = hub_index[nodes[i]], ib = hub_index[nodes[j]];
-        if (ia < 0 || ib < 0) { s_search = 1; continue; }
-        const uint32_t wbits = hub_bits[static_cast<int64_t>(ia) * hub_words + (ib >> 5)];
-        if (((wbits >> (ib & 31)) & 1u) && !((i == 0 && j == 1) || (i == 1 && j == 0))) {
-          atomicOr(&adj[i][j >> 5], 1u << (j & 31));
-          atomicOr(&adj[j][i >> 5], 1u << (i & 31));
+      // four independent bit-matrix words in flight per thread (one dependent level instead of three per entry:
+      // a hub-rich capped subgraph has ~100 big rows = 10 K entries, 78 per thread)
+      const int np = nbig * nbig;
+      for (int p0 = t; p0 < np; p0 += 4 * kSealBlock) {
+        uint32_t wv[4];
+        int ii4[4], jj4[4];
+        bool ok4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = p0 + q * kSealBlock;
+          const int a = p < np ? p / nbig : 0, b2 = p < np ? p - a * nbig : 0;
+          const bool take = p < np && a <= b2;
+          const int ia = hidx[a], ib = hidx[b2];
+          if (take && (ia < 0 || ib < 0)) s_search = 1;
+          ok4[q] = take && ia >= 0 && ib >= 0;
+          ii4[q] = big[a];
+          jj4[q] = big[b2];
+          wv[q] = ok4[q] ? hub_bits[static_cast<int64_t>(ia) * hub_words + (ib >> 5)] : 0u;
+          if (ok4[q] && !((wv[q] >> (ib & 31)) & 1u)) ok4[q] = false;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = ii4[q], j = jj4[q];
+          if (ok4[q] && !((i == 0 && j == 1) || (i == 1 && j == 0))) {
+            atomicOr(&adj[i][j >> 5], 1u << (j & 31));
+            atomicOr(&adj[j][i >> 5], 1u << (i & 31));
+          }
         }
       }
       __syncthreads();
@@ -1254,10 +1275,13 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   // fused: ceil(B / 8) workgroups for the pairs that need 128 threads, then one WAVE per pair (two per workgroup) for
   // the rest -- most of a batch.  Otherwise a workgroup per pair (the hardware dispatcher is the work queue: a static
   // share of ~24 pairs per persistent workgroup left the chip waiting for the unluckiest one, 0.755 vs 0.581 ms).
-  const int64_t grid = fused ? ceil_div(B, kDeferGroup) + ceil_div(B, kSealBlock / 64) : (B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
+  // team workgroups own 8 consecutive pairs on big batches (1/8 of the dispatches; most own no heavy pair at all), one pair
+  // on small ones (fb-pages-food's 4202 candidates are mostly heavy: 8 in series per workgroup left the chip idle)
+  const int group = B >= (int64_t(1) << 15) ? kDeferGroup : 1;
+  const int64_t grid = fused ? ceil_div(B, group) + ceil_div(B, kSealBlock / 64) : (B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
   hipLaunchKernelGGL(seal_subgraph_kernel, dim3(static_cast<unsigned>(grid)), dim3(kSealBlock), 0, st, adj_rowptr, adj_col,
                      n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag,
-                     tag_present, directed ? nullptr : hidx, hub_bits, static_cast<int>(hub_words), fused ? 1 : 0, directed);
+                     tag_present, directed ? nullptr : hidx, hub_bits, static_cast<int>(hub_words), fused ? group : 0, directed);
   return check_launch("seal_subgraphs");
 }
 
