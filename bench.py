@@ -260,7 +260,7 @@ def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5
             batch = seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=0)
             h1 = seal.first_layer_h1(batch, tag_map, T, e, gw[0], check=False)       # X W_1 from two row gathers, X never built
             a16, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
-            return seal.head(None, key, batch.node_off(), hw, a_all=a16)[1]
+            return seal.head(None, key, batch.node_off(), hw, a_all=a16, check=False)[1]   # indices checked once, after the loop
 
         # No collective in here: a rank that fails must not leave the others hanging at a barrier and take the
         # headline line down with it.  Scores stay sharded (gather=False; the all_gather is 4 B per scored edge);
@@ -273,6 +273,8 @@ def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5
             s = scorer(pairs, gather=False)
         torch.cuda.synchronize()
         timings[name] = (time.perf_counter() - t0) / iters
+        from lpgnn_amd import ops as _ops
+        _ops.raise_if_flagged(torch.device(device), "seal forward index")     # the forwards' deferred index check
         assert s.shape[0] == lo_hi[1] - lo_hi[0]
     dt = timings["bf16"]
     return {"workload": f"synthetic collab-shaped SEAL scoring forward: |V|={N}, {E} undirected edges, {pairs_per_gpu} candidate "

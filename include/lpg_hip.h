@@ -406,7 +406,7 @@ int lpg_seal_h1_tables_bf16(const int32_t* nodes, const int64_t* node_off, const
  * (tag_present may be NULL: no map); head [4] = {total vertices, *err_flag, T, largest present tag (0 without tag_present)} for the caller's single host
  * read.  first (may be NULL; capacity ceil(B * 128 / window_rows) + 1 entries is always enough, the number written
  * is ceil(total / window_rows) + 1) receives the row windows of lpg_seal_conv_windows in the same launch.
- * Workspace only for B > 2^18 (lpg_seal_batch_index_bytes). */
+ * Workspace only for B > 2^14 (lpg_seal_batch_index_bytes). */
 int64_t lpg_seal_batch_index_bytes(int64_t B);
 int lpg_seal_batch_index(const int32_t* n_nodes, int64_t B, int64_t* node_off, const uint8_t* tag_present,
                          int64_t n_tags, int32_t* tag_map, const int32_t* err_flag, int64_t* head,

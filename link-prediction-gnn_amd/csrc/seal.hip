@@ -1131,7 +1131,8 @@ __global__ __launch_bounds__(kBlock) void seal_logits_kernel(const float* __rest
 // one 4-word head {total vertices, error flag, distinct tags, 0} for the batch's single host read.  One launch, two
 // workgroups (a dozen tiny scan / elementwise launches before: 40 of the 210 us of fb-pages-food's structure stage).
 constexpr int kIdxBlock = 1024;
-constexpr int64_t kIdxOneBlockMax = int64_t(1) << 18;     // beyond: the sizes are scanned by rocPRIM first
+constexpr int64_t kIdxOneBlockMax = int64_t(1) << 14;     // beyond: the sizes are scanned by rocPRIM first (one workgroup takes ~2 us
+                                                          // per 4096 sizes, serially: 55 us at 100 K subgraphs, and the whole forward waits for the total)
 
 __device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
 #pragma unroll

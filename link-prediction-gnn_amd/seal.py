@@ -575,7 +575,7 @@ def _folded_conv2_dense(hw, k):
     return out
 
 
-def head(z, key, node_off, hw, a_all=None):
+def head(z, key, node_off, hw, a_all=None, check=True):
     """The DGCNN head of SEAL/model/gnn.py:82-137, batched over all subgraphs:
     SortPooling -> conv1d(96->16, stride 96) -> conv1d(width 5, 16->32) -> dense 128 relu -> dense 2
     -> softmax.  Every stage is one launch on the whole batch.  Neither convolution has an activation: conv1d #1
@@ -584,7 +584,8 @@ def head(z, key, node_off, hw, a_all=None):
     hw: dict with conv1d_kernel_1 [96,1,16], conv1d_kernel_2 [5,16,32], weight_1 [448,128], bias_1,
     weight_2 [128,2], bias_2 (the shipped checkpoint's tensors).  Returns (pre_y [B,2], score [B]).
     a_all: z @ conv1d_kernel_1 [total, 16] when the conv stack already produced it (graph_conv_stack(head_k1=));
-    z may then be None."""
+    z may then be None.  check=False: the forward's deferred index check (one host sync) is left to the caller --
+    ops.raise_if_flagged(device) after a scoring loop -- so consecutive forwards queue up without a gap."""
     lib = _lib.load()
     k1 = hw["conv1d_kernel_1"].reshape(-1, hw["conv1d_kernel_1"].shape[-1])          # [96, 16]
     fw, c1, c2 = hw["conv1d_kernel_2"].shape
@@ -610,7 +611,8 @@ def head(z, key, node_off, hw, a_all=None):
     else:
         pre_y = _ops.linear(dense, hw["weight_2"], hw["bias_2"], w_is_km=True)
         _lib.check(lib.lpg_softmax2_pos_score_f32(_ops._ptr(pre_y), B, _ops._ptr(score), _ops._stream()), "softmax2")
-    _ops.maybe_check(a.device, "seal forward index")       # the one deferred check of the scoring forward
+    if check:
+        _ops.maybe_check(a.device, "seal forward index")   # the one deferred check of the scoring forward
     return pre_y, score
 
 

@@ -1010,7 +1010,7 @@ def test_spmm_large_rmat_properties(dev):
 
 @pytest.mark.parametrize("B", [0, 1, 5, 4096, 4097, 100_000, 300_000])
 def test_seal_batch_index(dev, B):
-    """lpg_seal_batch_index: node offsets == exclusive cumsum of the sizes (one workgroup up to 2^18 subgraphs, rocPRIM
+    """lpg_seal_batch_index: node offsets == exclusive cumsum of the sizes (one workgroup up to 2^14 subgraphs, rocPRIM
     beyond), tag map == ranks of the present tags, head == {total, flag, T, 0}."""
     from lpgnn_amd import seal, ops
     rng = np.random.default_rng(B + 3)
