@@ -40,6 +40,8 @@ constexpr int HS = 256 + 8;           // row stride of a transposed bf16 plane (
 // tanh(v) = 1 - 2 / (exp(2 v) + 1): v_exp_f32 and v_rcp_f32 (1 ulp each; __frcp_rn expands to the ten-instruction IEEE division
 // sequence, 16 times per tile and layer): |error| < 4e-7 absolute on an output in [-1, 1]; saturates cleanly
 __device__ __forceinline__ float tanh_fast_div(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
+// the same with the row scale folded into the exponent: tanh(acc * s) = 1 - 2 / (2^(acc * s2) + 1), s2 = s * 2 log2(e)
+__device__ __forceinline__ float tanh_scaled(float acc, float s2) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc * s2) + 1.0f); }
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
@@ -82,7 +84,7 @@ template <> struct KTerms<3> : Terms<3> {};
 
 struct RowCtxT {
   int i, start;        // vertex index inside its subgraph (-100000: no row), the subgraph's first local row
-  float one;           // D^-1 of the row (0: no row)
+  float one;           // D^-1 of the row times 2 log2(e) (0: no row)
   uint32_t dadd;       // what "+ 1.0" is on the diagonal's bf16: 0x0080 when it already holds 1.0 (self loop), else 0x3F80
   uint32_t b0, b1, b2, b3;
   int j_lo, j_hi;      // column tiles the tile's subgraphs overlap
@@ -213,7 +215,8 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
       const uint4 q4 = *reinterpret_cast<const uint4*>(adj_bits + (static_cast<int64_t>(bf + q) * MAXN + c.i) * WORDS);
       c.b0 = q4.x; c.b1 = q4.y; c.b2 = q4.z; c.b3 = q4.w;
       const int pc = __popc(c.b0) + __popc(c.b1) + __popc(c.b2) + __popc(c.b3);
-      c.one = static_cast<float>(1.0 / static_cast<double>(pc + 1));             // D^-1 = 1 / rowsum(A + I)
+      // D^-1 = 1 / rowsum(A + I) (fp32 division of small integers is exact to rounding), times 2 log2(e) for tanh_scaled
+      c.one = (1.0f / static_cast<float>(pc + 1)) * 2.885390081777927f;
       const uint32_t wi = c.i < 32 ? c.b0 : (c.i < 64 ? c.b1 : (c.i < 96 ? c.b2 : c.b3));
       c.dadd = ((wi >> (c.i & 31)) & 1u) ? 0x0080u : 0x3F80u;
     }
@@ -222,10 +225,11 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
   const RowCtxT ctx0 = row_ctx(wave), ctx1 = row_ctx(wave + kConvBlock / 64);
 
   // Z^T of a row tile: tanh(D^-1 sum_J H_J^T (A + I)_{IJ}^T); lane = vertex, register i = feature acc_row(i, h)
-  auto aggregate = [&](const RowCtxT& cx) {
-    f32x16 acc;
+  f32x16 zero16;                                     // one zero accumulator for the first MFMA of every chain (D != C is allowed)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+  auto aggregate = [&](const RowCtxT& cx) {
+    f32x16 acc = zero16;
     for (int J = cx.j_lo; J <= cx.j_hi; ++J) {
       const int p0 = 32 * J - cx.start;
       const int w = p0 >> 5, sh = p0 & 31;           // arithmetic shift: p0 may be negative
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = tanh_fast_div(acc[i] * cx.one);
+    for (int i = 0; i < 16; ++i) acc[i] = tanh_scaled(acc[i], cx.one);       // cx.one carries D^-1 * 2 log2(e)
     return acc;
   };
 
@@ -327,9 +331,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
         }
       }
       // H'^T = W^T Z^T
-      f32x16 hn;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) hn[i] = 0.f;
+      f32x16 hn = zero16;
       const bool merged = k1 && layer == 3;          // 32 -> 1 (w4) rides in row 16 of the conv1d #1 product
       if (layer < 3) {
 #pragma unroll
