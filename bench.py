@@ -197,9 +197,8 @@ def seal_forward_bench(device, iters=10):
         return seal.link2subgraph(pos, neg, 620, 0.1, 1, device=device)
 
     def aggregate(batch, tag_map, T):
-        h1 = seal.first_layer_h1(batch, tag_map, T, emb, weights[0], check=False)  # X W_1 from two row gathers, X never built
-        a16, key = seal.graph_conv_stack(None, None, None, weights, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
-        return seal.head(None, key, batch.node_off(), hw, a_all=a16)[1]       # P(link) per candidate
+        pooled = seal.score_stack(batch, tag_map, T, emb, weights, k1, pool_k=18)     # tables -> 4 graph convs -> conv1d #1 -> SortPooling
+        return seal.head(None, None, batch.node_off(), hw, pooled=pooled)[1]       # P(link) per candidate
 
     batch, _, T, tag_map, _ = structure()
     aggregate(batch, tag_map, T)
@@ -258,9 +257,9 @@ def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5
 
         def score_fn(p):
             batch = seal.extract_subgraphs(p, graph, 1, cap_policy="device", seed=0)
-            h1 = seal.first_layer_h1(batch, tag_map, T, e, gw[0], check=False)       # X W_1 from two row gathers, X never built
-            a16, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1)   # dense stack + conv1d #1
-            return seal.head(None, key, batch.node_off(), hw, a_all=a16, check=False)[1]   # indices checked once, after the loop
+            # tags / nodes in, pooled rows out: layer 1 from the two tables, four graph convolutions, conv1d #1, SortPooling
+            pooled = seal.score_stack(batch, tag_map, T, e, gw, k1, pool_k=k)
+            return seal.head(None, None, batch.node_off(), hw, pooled=pooled, check=False)[1]   # indices checked once, after the loop
 
         # No collective in here: a rank that fails must not leave the others hanging at a barrier and take the
         # headline line down with it.  Scores stay sharded (gather=False; the all_gather is 4 B per scored edge);

@@ -431,6 +431,29 @@ int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* first, int6
                              const uint16_t* w2, const uint16_t* w3, const uint16_t* w4, uint16_t* cat,
                              int64_t ldc, float* key, const float* head_k1, float* head_a16,
                              void* stream);
+/* The scoring form of the same stack with both ends fused (round 2): the conv1d #1 fusion is mandatory
+ * (head_k1 [96,16]) and
+ *  - h1 == NULL: layer 1 comes from the two tables of lpg_seal_h1_tables_* gathered in the kernel's prologue (nodes,
+ *    tags [B,128] from lpg_seal_subgraphs; tag_map / T / w1_tag [T,32] / p_table [n_graph,32] as there) -- H_1 is
+ *    neither written nor read back; bit for bit what lpg_seal_h1_tables_* + the h1 form computes;
+ *  - pooled != NULL: SortPooling (SEAL/model/gnn.py:82-91; the total order of lpg_seal_sortpool_f32) of the 16-wide
+ *    rows runs in the epilogue and the kernel writes pooled [B, pool_k, 16]; key / head_a16 may then be NULL.
+ * Either fusion can be left out (h1 given / pooled NULL: key and head_a16 are written as by lpg_seal_conv_stack_*).
+ * err_flag: OR-ed with LPG_F_INDEX_RANGE when a tag or node of a row is out of range (the row is then zero). */
+int lpg_seal_score_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
+                             const uint32_t* adj_bits, const float* h1, int64_t ldh, const int32_t* nodes,
+                             const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len, int64_t T,
+                             const float* w1_tag, const float* p_table, int64_t n_graph, const float* w2,
+                             const float* w3, const float* w4, const float* head_k1, float* key,
+                             float* head_a16, float* pooled, int64_t pool_k, int32_t* err_flag,
+                             void* stream);
+int lpg_seal_score_stack_bf16(const int64_t* node_off, const int32_t* first, int64_t n_windows,
+                              const uint32_t* adj_bits, const uint16_t* h1, int64_t ldh,
+                              const int32_t* nodes, const int32_t* tags, const int32_t* tag_map,
+                              int64_t tag_map_len, int64_t T, const float* w1_tag, const float* p_table,
+                              int64_t n_graph, const uint16_t* w2, const uint16_t* w3, const uint16_t* w4,
+                              const float* head_k1, float* key, float* head_a16, float* pooled,
+                              int64_t pool_k, int32_t* err_flag, void* stream);
 
 /* The DGCNN head's last dense layer and its softmax in one launch (SEAL/model/gnn.py:127-137): pre_y [B, 2] =
  * h [B, H] @ w [H, 2] + bias [2] (w as TensorFlow stores it, input index major), score [B] = softmax(pre_y)[:, 1]. */

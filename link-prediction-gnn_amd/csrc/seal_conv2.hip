@@ -82,6 +82,25 @@ template <> struct KTerms<1> {
 };
 template <> struct KTerms<3> : Terms<3> {};
 
+// the two fusions at the ends of the stack (either may be off):
+//  * tables mode (h1 == nullptr): H_1 = W_1[tag] + P[node] is gathered in the prologue -- what lpg_seal_h1_tables_* writes
+//    to HBM and this kernel would read back (187 MB each way per 100 K candidates, one launch);
+//  * pooled != nullptr (with head_k1): SortPooling (SEAL/model/gnn.py:82-91) of the head's 16-wide rows runs in the
+//    epilogue -- a workgroup owns whole subgraphs, the rows and sort keys are in its registers -- and the kernel writes
+//    pooled [B, pool_k, 16] instead of a16 [total, 16] and key [total] (lpg_seal_sortpool_f32: another launch).
+struct ConvFuse {
+  const int32_t* nodes;      // [B, 128] subgraph vertices' graph node ids
+  const int32_t* tags;       // [B, 128] raw DRNL tags
+  const int32_t* tag_map;    // raw tag -> column of the one-hot block (may be null: tags are used as they are)
+  int64_t tag_map_len, T;
+  const float* w1_tag;       // [T, 32] the tag rows of W_1
+  const float* p_table;      // [n_graph, 32] emb @ W_1[T:]
+  int64_t n_graph;
+  float* pooled;             // [B, pool_k, 16]
+  int pool_k;
+  int32_t* err_flag;
+};
+
 struct RowCtxT {
   int i, start;        // vertex index inside its subgraph (-100000: no row), the subgraph's first local row
   float one;           // D^-1 of the row times 2 log2(e) (0: no row)
@@ -95,7 +114,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
     const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
     const TIN* __restrict__ h1, int64_t ldh, const TIN* __restrict__ w2, const TIN* __restrict__ w3,
     const TIN* __restrict__ w4, TIN* __restrict__ cat, int64_t ldc, float* __restrict__ key,
-    const float* __restrict__ k1, float* __restrict__ a16) {
+    const float* __restrict__ k1, float* __restrict__ a16, const ConvFuse fx) {
   __shared__ __attribute__((aligned(16))) uint16_t Hp[NP][32][HS];     // H^T as NP bf16 planes
   __shared__ __attribute__((aligned(16))) uint4 lut[256];             // byte -> 8 x bf16 {0, 1}
   __shared__ __attribute__((aligned(16))) uint4 Wb[2][NP][2][64];     // W_2, W_3: A fragments [layer][plane][k step][lane]
@@ -103,6 +122,8 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
   __shared__ __attribute__((aligned(16))) uint4 W4b[NP][2][2];        // w4 alone (no head fusion): [plane][k step][h], row 0
   __shared__ uint32_t rinfo[RMAX];
   __shared__ int soff[WIN + 2];
+  __shared__ int32_t rnode[RMAX];                   // tables mode: the row's graph node (-1: invalid) ...
+  __shared__ uint16_t rtag[RMAX];                   // ... and its column in the one-hot block
   __shared__ __attribute__((aligned(16))) float zt[CAT ? kConvBlock / 64 : 1][CAT ? 16 : 1][36];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -114,28 +135,37 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
   const int ntiles = (nrows + 31) >> 5;             // <= 8
 
   // ---- H_1 planes: a wave-sized group of items covers 16 row pairs x 4 feature quads (half a 32-row tile, half the
-  // features): lane (i = l & 15, q = l >> 4) reads the 16-byte pieces [4 kq, 4 kq + 4) of rows 2 rp and 2 rp + 1 and
+  // features): lane (i = l & 15, q = l >> 4) takes the 16-byte pieces [4 kq, 4 kq + 4) of rows 2 rp and 2 rp + 1 and
   // writes 12 (or 4) row-pair dwords; dword index = feature * 132 + rp, so the 64 lanes of a write hit 64 banks.
-  for (int idx = tid; idx < ntiles * 128; idx += kConvBlock) {
-    const int g = idx >> 6, l = idx & 63;
-    const int rp = (g >> 1) * 16 + (l & 15), kq = (g & 1) * 4 + (l >> 4), row = 2 * rp;
-    float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};   // rows past the end are zero (0 x NaN is not)
-    if constexpr (sizeof(TIN) == 4) {
-      if (row < nrows) { const float4 q = *reinterpret_cast<const float4*>(h1 + (r_lo + row) * ldh + 4 * kq); v0[0] = q.x; v0[1] = q.y; v0[2] = q.z; v0[3] = q.w; }
-      if (row + 1 < nrows) { const float4 q = *reinterpret_cast<const float4*>(h1 + (r_lo + row + 1) * ldh + 4 * kq); v1[0] = q.x; v1[1] = q.y; v1[2] = q.z; v1[3] = q.w; }
-    } else {
-      if (row < nrows) { const uint2 q = *reinterpret_cast<const uint2*>(h1 + (r_lo + row) * ldh + 4 * kq); v0[0] = bf16_to_f32(q.x & 0xFFFFu); v0[1] = bf16_to_f32(q.x >> 16); v0[2] = bf16_to_f32(q.y & 0xFFFFu); v0[3] = bf16_to_f32(q.y >> 16); }
-      if (row + 1 < nrows) { const uint2 q = *reinterpret_cast<const uint2*>(h1 + (r_lo + row + 1) * ldh + 4 * kq); v1[0] = bf16_to_f32(q.x & 0xFFFFu); v1[1] = bf16_to_f32(q.x >> 16); v1[2] = bf16_to_f32(q.y & 0xFFFFu); v1[3] = bf16_to_f32(q.y >> 16); }
-    }
+  // `piece(row, kq, v)` yields the four values: a 16-byte read of h1, or (tables mode, after the row table below) the
+  // sum of two 16-byte gathers.
+  auto fill_planes = [&](auto piece) {
+    for (int idx = tid; idx < ntiles * 128; idx += kConvBlock) {
+      const int g = idx >> 6, l = idx & 63;
+      const int rp = (g >> 1) * 16 + (l & 15), kq = (g & 1) * 4 + (l >> 4), row = 2 * rp;
+      float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};   // rows past the end are zero (0 x NaN is not)
+      if (row < nrows) piece(row, kq, v0);
+      if (row + 1 < nrows) piece(row + 1, kq, v1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t a[NP], b[NP];
-      planes_of<NP>(v0[j], a);
-      planes_of<NP>(v1[j], b);
+      for (int j = 0; j < 4; ++j) {
+        uint32_t a[NP], b[NP];
+        planes_of<NP>(v0[j], a);
+        planes_of<NP>(v1[j], b);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kq + j][row]) = a[p] | (b[p] << 16);
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kq + j][row]) = a[p] | (b[p] << 16);
+      }
     }
-  }
+  };
+  if (h1)
+    fill_planes([&](int row, int kq, float (&v)[4]) {
+      if constexpr (sizeof(TIN) == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(h1 + (r_lo + row) * ldh + 4 * kq);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+        const uint2 q = *reinterpret_cast<const uint2*>(h1 + (r_lo + row) * ldh + 4 * kq);
+        v[0] = bf16_to_f32(q.x & 0xFFFFu); v[1] = bf16_to_f32(q.x >> 16); v[2] = bf16_to_f32(q.y & 0xFFFFu); v[3] = bf16_to_f32(q.y >> 16);
+      }
+    });
   {                                                 // byte -> 8 bf16 (bit j set -> 1.0 = 0x3F80 in element j)
     uint32_t d[4];
 #pragma unroll
@@ -199,6 +229,34 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
   for (int q = tid; q < nsub; q += kConvBlock)
     for (int lr = soff[q]; lr < soff[q + 1]; ++lr) rinfo[lr] = (static_cast<uint32_t>(q) << 8) | static_cast<uint32_t>(lr - soff[q]);
   __syncthreads();
+  if (!h1) {
+    // tables mode: per row its (node, tag column), then the planes from W_1[tag] + P[node] (fp32 sum; NP = 1 rounds it
+    // once to bf16 -- bit for bit what lpg_seal_h1_tables_f32 / _bf16 followed by the h1 read above gives)
+    for (int lr = tid; lr < nrows; lr += kConvBlock) {
+      const uint32_t ri = rinfo[lr];
+      const int64_t slot = static_cast<int64_t>(bf + (ri >> 8)) * MAXN + (ri & 255u);
+      int32_t tg = fx.tags[slot];
+      const int32_t nd = fx.nodes[slot];
+      bool ok = true;
+      if (fx.tag_map) {
+        ok = tg >= 0 && tg < fx.tag_map_len;
+        tg = fx.tag_map[ok ? tg : 0];
+      }
+      ok = ok && tg >= 0 && tg < fx.T && nd >= 0 && nd < fx.n_graph;
+      if (!ok) flag_error(fx.err_flag, LPG_F_INDEX_RANGE);
+      rnode[lr] = ok ? nd : -1;
+      rtag[lr] = static_cast<uint16_t>(ok ? tg : 0);
+    }
+    __syncthreads();
+    fill_planes([&](int row, int kq, float (&v)[4]) {
+      const int32_t nd = rnode[row];
+      if (nd < 0) return;                              // an invalid row stays zero, as the tables kernel leaves it
+      const float4 a = *reinterpret_cast<const float4*>(fx.w1_tag + static_cast<int64_t>(rtag[row]) * 32 + 4 * kq);
+      const float4 q = *reinterpret_cast<const float4*>(fx.p_table + static_cast<int64_t>(nd) * 32 + 4 * kq);
+      v[0] = a.x + q.x; v[1] = a.y + q.y; v[2] = a.z + q.z; v[3] = a.w + q.w;
+    });
+    __syncthreads();
+  }
 
   auto row_ctx = [&](int I) {
     RowCtxT c{-100000, 0, 0.f, 0x3F80u, 0u, 0u, 0u, 0u, 0, -1};
@@ -266,6 +324,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
   f32x16 aa0, aa1;                                   // a16^T tiles (head fusion)
 #pragma unroll
   for (int i = 0; i < 16; ++i) aa0[i] = aa1[i] = 0.f;
+  float kreg0 = 0.f, kreg1 = 0.f;                    // the tiles' sort keys (layer 4, feature 0), kept for the pooling epilogue
 #pragma unroll 1
   for (int layer = 1; layer <= 4; ++layer) {
     f32x16 hn0, hn1;
@@ -276,7 +335,8 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
       const f32x16 z = aggregate(t == 0 ? ctx0 : ctx1);
       const int lr = 32 * I + r;
       if (layer == 4) {
-        if (h == 0 && lr < nrows) key[r_lo + lr] = z[0];            // feature 0
+        if (t == 0) kreg0 = z[0]; else kreg1 = z[0];               // feature 0
+        if (key && h == 0 && lr < nrows) key[r_lo + lr] = z[0];
         continue;
       }
       if constexpr (CAT) {
@@ -363,7 +423,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
             aa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&kv), zb[KTerms<NP>::zp[q]][s2], aa, 0, 0, 0);
           }
         if (t == 0) aa0 = aa; else aa1 = aa;
-        if (layer == 3 && lr < nrows) {              // outputs c = acc_row(i, h) < 16  <=>  i < 8
+        if (layer == 3 && a16 && lr < nrows) {       // outputs c = acc_row(i, h) < 16  <=>  i < 8
           *reinterpret_cast<float4*>(a16 + (r_lo + lr) * 16 + 4 * h) = make_float4(aa[0], aa[1], aa[2], aa[3]);
           *reinterpret_cast<float4*>(a16 + (r_lo + lr) * 16 + 8 + 4 * h) = make_float4(aa[4], aa[5], aa[6], aa[7]);
         }
@@ -396,20 +456,96 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
     }
     __syncthreads();
   }
+  if (fx.pooled && k1) {
+    // ---- SortPooling in the epilogue (SEAL/model/gnn.py:82-91): per subgraph the pool_k rows with the largest keys,
+    // key descending, ties by vertex index, NaN last (the total order of seal_sortpool_kernel); missing rows are zero.
+    // The 16-wide rows and the keys move from the accumulators into LDS on top of the planes and the bit table, which
+    // nobody reads any more.
+    float* As = reinterpret_cast<float*>(&Hp[0][0][0]);               // [nrows][16]: <= 16 320 B <= one plane
+    // [nrows] sort composites: (order-preserving integer image of the key) << 8 | (127 - vertex index) -- "a comes before b"
+    // is ONE unsigned 64-bit compare (the float form with its NaN and tie rules cost ~10 VALU instructions per key in a
+    // kernel that is VALU-bound: +20 %).  NaN -> 0 (last), -0 -> +0 (a tie with +0, as `==` has it).
+    unsigned long long* comp = reinterpret_cast<unsigned long long*>(&lut[0]);
+    __syncthreads();                                                  // every wave is past its last read of Hp / lut
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int I = wave + t * (kConvBlock / 64);
+      const int lr = 32 * I + r;
+      if (I < ntiles && lr < nrows) {
+        const f32x16& aa = t == 0 ? aa0 : aa1;
+        if (h == 0) {
+          const float kf = (t == 0 ? kreg0 : kreg1) + 0.0f;
+          uint32_t u = __float_as_uint(kf);
+          u = (kf != kf) ? 0u : (u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u));
+          comp[lr] = (static_cast<unsigned long long>(u) << 8) | static_cast<unsigned long long>(127 - static_cast<int>(rinfo[lr] & 255u));
+        }
+        *reinterpret_cast<float4*>(As + lr * 16 + 4 * h) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+        *reinterpret_cast<float4*>(As + lr * 16 + 8 + 4 * h) = make_float4(aa[4], aa[5], aa[6], aa[7]);
+      }
+    }
+    __syncthreads();
+    const int pk = fx.pool_k;
+    for (int lr = tid; lr < nrows; lr += kConvBlock) {                // one thread per vertex: its rank inside its subgraph
+      const uint32_t ri = rinfo[lr];
+      const int q = static_cast<int>(ri >> 8), s0 = soff[q], n = soff[q + 1] - s0;
+      const unsigned long long mine = comp[lr];
+      int rank = 0;
+#pragma unroll 4
+      for (int j = 0; j < n; ++j) rank += comp[s0 + j] > mine ? 1 : 0;
+      rtag[lr] = static_cast<uint16_t>(rank);         // (the tag columns are not needed any more)
+    }
+    __syncthreads();
+    // the kept rows leave as whole 64-byte pieces: four lanes per row, 16 rows per wave instruction (a thread per row
+    // writing its four 16-byte pieces one after the other touched 64 different lines per instruction)
+    for (int idx = tid; idx < nrows * 4; idx += kConvBlock) {
+      const int lr = idx >> 2, rank = rtag[lr];
+      if (rank < pk) {
+        const int q = static_cast<int>(rinfo[lr] >> 8);
+        reinterpret_cast<float4*>(fx.pooled + (static_cast<int64_t>(bf + q) * pk + rank) * 16)[idx & 3] =
+            reinterpret_cast<const float4*>(As + lr * 16)[idx & 3];
+      }
+    }
+    // subgraphs with fewer than pool_k vertices (most of them): zero rows, one 16-byte piece per thread and step (a thread
+    // per subgraph writing its ~10 rows in series was as slow as the separate SortPooling launch)
+    for (int idx = tid; idx < nsub * pk * 4; idx += kConvBlock) {
+      const int q = idx / (pk * 4), rem = idx - q * (pk * 4), rr = rem >> 2;
+      if (rr >= soff[q + 1] - soff[q])
+        reinterpret_cast<float4*>(fx.pooled + (static_cast<int64_t>(bf + q) * pk + rr) * 16)[rem & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 }
 
 template <int NP, typename TIN>
 int launch_conv2(const int64_t* node_off, const int32_t* first, int64_t n_windows, const uint32_t* adj_bits, const TIN* h1,
                  int64_t ldh, const TIN* w2, const TIN* w3, const TIN* w4, TIN* cat, int64_t ldc, float* key,
-                 const float* head_k1, float* head_a16, hipStream_t st) {
+                 const float* head_k1, float* head_a16, const ConvFuse& fx, hipStream_t st) {
   const dim3 grid(static_cast<unsigned>(n_windows)), blk(kConvBlock);
   if (cat)
     hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, true>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat,
-                       ldc, key, head_k1, head_a16);
+                       ldc, key, head_k1, head_a16, fx);
   else
     hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, false>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4,
-                       cat, ldc, key, head_k1, head_a16);
+                       cat, ldc, key, head_k1, head_a16, fx);
   return check_launch("seal_conv_stack");
+}
+
+// argument checks shared by the fused entry points; fills fx
+int make_fuse(ConvFuse* fx, bool have_h1, const int32_t* nodes, const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len,
+              int64_t T, const float* w1_tag, const float* p_table, int64_t n_graph, const float* head_k1, float* pooled,
+              int64_t pool_k, float* key, float* head_a16, void* cat, int32_t* err_flag) {
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  if (!have_h1) {
+    LPG_REQUIRE(nodes && tags && w1_tag && p_table && T >= 1 && T < 65536 && n_graph >= 1 && tag_map_len >= 0 && (tag_map || tag_map_len == 0),
+                "seal_score_stack: without h1 the stack needs nodes, tags, w1_tag, p_table (1 <= T < 65536)");
+    LPG_REQUIRE(al16(w1_tag) && al16(p_table), "seal_score_stack: tables must be 16-byte aligned");
+  }
+  if (pooled) {
+    LPG_REQUIRE(head_k1 && pool_k >= 1 && pool_k <= MAXN && al16(pooled), "seal_score_stack: pooled needs head_k1, 1 <= pool_k <= %d, 16-byte alignment", MAXN);
+  } else {
+    LPG_REQUIRE(key && (cat || head_k1) && (!head_k1 || head_a16), "seal_score_stack: without pooled the stack needs key and cat or head_a16");
+  }
+  *fx = ConvFuse{nodes, tags, tag_map, tag_map_len, T, w1_tag, p_table, n_graph, pooled, static_cast<int>(pool_k), err_flag};
+  return LPG_OK;
 }
 }  // namespace
 
@@ -417,9 +553,49 @@ namespace lpg {
 int seal_conv2_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows, const uint32_t* adj_bits,
                    const float* h1, int64_t ldh, const float* w2, const float* w3, const float* w4, float* cat, int64_t ldc,
                    float* key, const float* head_k1, float* head_a16, hipStream_t st) {
-  return launch_conv2<3, float>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16, st);
+  return launch_conv2<3, float>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16,
+                                ConvFuse{}, st);
 }
 }  // namespace lpg
+
+// ---- the scoring stack with both ends fused: tags / nodes in, pooled rows out
+LPG_EXPORT int lpg_seal_score_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
+                                        const uint32_t* adj_bits, const float* h1, int64_t ldh, const int32_t* nodes,
+                                        const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len, int64_t T,
+                                        const float* w1_tag, const float* p_table, int64_t n_graph, const float* w2,
+                                        const float* w3, const float* w4, const float* head_k1, float* key, float* head_a16,
+                                        float* pooled, int64_t pool_k, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && (!h1 || (ldh >= 32 && ldh % 4 == 0)), "seal_score_stack: bad sizes");
+  if (n_windows == 0) return LPG_OK;
+  LPG_REQUIRE(node_off && first && adj_bits && w2 && w3 && w4, "seal_score_stack: null pointer");
+  LPG_REQUIRE((!h1 || reinterpret_cast<uintptr_t>(h1) % 16 == 0) && (!head_a16 || reinterpret_cast<uintptr_t>(head_a16) % 16 == 0),
+              "seal_score_stack: h1 / head_a16 must be 16-byte aligned");
+  ConvFuse fx;
+  if (int rc = make_fuse(&fx, h1 != nullptr, nodes, tags, tag_map, tag_map_len, T, w1_tag, p_table, n_graph, head_k1, pooled, pool_k,
+                         key, head_a16, nullptr, err_flag)) return rc;
+  LPG_REQUIRE(head_k1, "seal_score_stack: head_k1 is required (the concat form is lpg_seal_conv_stack_f32)");
+  return launch_conv2<3, float>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, nullptr, 96, key, head_k1, head_a16, fx,
+                                as_stream(stream));
+}
+
+LPG_EXPORT int lpg_seal_score_stack_bf16(const int64_t* node_off, const int32_t* first, int64_t n_windows,
+                                         const uint32_t* adj_bits, const uint16_t* h1, int64_t ldh, const int32_t* nodes,
+                                         const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len, int64_t T,
+                                         const float* w1_tag, const float* p_table, int64_t n_graph, const uint16_t* w2,
+                                         const uint16_t* w3, const uint16_t* w4, const float* head_k1, float* key,
+                                         float* head_a16, float* pooled, int64_t pool_k, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && (!h1 || (ldh >= 32 && ldh % 4 == 0)), "seal_score_stack_bf16: bad sizes");
+  if (n_windows == 0) return LPG_OK;
+  LPG_REQUIRE(node_off && first && adj_bits && w2 && w3 && w4, "seal_score_stack_bf16: null pointer");
+  LPG_REQUIRE((!h1 || reinterpret_cast<uintptr_t>(h1) % 8 == 0) && (!head_a16 || reinterpret_cast<uintptr_t>(head_a16) % 16 == 0),
+              "seal_score_stack_bf16: h1 must be 8-byte, head_a16 16-byte aligned");
+  ConvFuse fx;
+  if (int rc = make_fuse(&fx, h1 != nullptr, nodes, tags, tag_map, tag_map_len, T, w1_tag, p_table, n_graph, head_k1, pooled, pool_k,
+                         key, head_a16, nullptr, err_flag)) return rc;
+  LPG_REQUIRE(head_k1, "seal_score_stack_bf16: head_k1 is required (the concat form is lpg_seal_conv_stack_bf16)");
+  return launch_conv2<1, uint16_t>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, nullptr, 96, key, head_k1, head_a16, fx,
+                                   as_stream(stream));
+}
 
 LPG_EXPORT int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* first, int64_t n_windows,
                                         const uint32_t* adj_bits, const uint16_t* h1, int64_t ldh, const uint16_t* w2,
@@ -434,5 +610,5 @@ LPG_EXPORT int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* 
   LPG_REQUIRE(al(h1, 8) && (!cat || al(cat, 8)) && (!head_a16 || al(head_a16, 16)),
               "seal_conv_stack_bf16: h1 / cat must be 8-byte aligned, head_a16 16-byte aligned");
   return launch_conv2<1, uint16_t>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16,
-                                   as_stream(stream));
+                                   ConvFuse{}, as_stream(stream));
 }

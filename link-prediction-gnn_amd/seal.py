@@ -438,6 +438,23 @@ def _block_csr(lib, batch, off, total, fold_dinv):
 _p_table_cache = {}
 
 
+def _h1_tables(tags_size, emb, w1):
+    """(p_table [n_graph, 32] fp32, w1_tag [T, 32] fp32, bf16?) -- the two tables layer 1 is gathered from, built once
+    per (emb, W_1, T) version (for bf16 inputs: the fp32 products of the bf16 values)."""
+    T = int(tags_size)
+    bf16 = emb.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
+    if w1.shape[1] != 32 or w1.shape[0] != T + emb.shape[1]:
+        raise ValueError(f"first_layer_h1: W_1 must be [{T + emb.shape[1]}, 32], got {tuple(w1.shape)}")
+    ck = (emb.data_ptr(), emb._version, w1.data_ptr(), w1._version, T, tuple(emb.shape), bf16)
+    hit = _p_table_cache.get(ck)
+    if hit is None:
+        if len(_p_table_cache) > 4:
+            _p_table_cache.clear()
+        w1f, embf = _ops._c(w1, torch.float32), _ops._c(emb, torch.float32)
+        hit = _p_table_cache[ck] = (_ops.linear(embf, w1f[T:], w_is_km=True), w1f[:T].contiguous(), emb, w1)   # keeps the keys alive
+    return hit[0], hit[1], bf16
+
+
 def first_layer_h1(batch, tag_map, tags_size, emb, w1, check=True):
     """H_1 = X W_1 for X = [onehot(tag) || emb[node]] WITHOUT building X (SEAL/config/data.py:129-140 +
     SEAL/model/gnn.py:46): a one-hot row times W_1 is a row of W_1, and emb[node] @ W_1[T:] is row `node` of
@@ -446,19 +463,7 @@ def first_layer_h1(batch, tag_map, tags_size, emb, w1, check=True):
     once to bf16 -- bf16(X W_1) with fp32 accumulation."""
     lib = _lib.load()
     T = int(tags_size)
-    bf16 = emb.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
-    if w1.shape[1] != 32 or w1.shape[0] != T + emb.shape[1]:
-        raise ValueError(f"first_layer_h1: W_1 must be [{T + emb.shape[1]}, 32], got {tuple(w1.shape)}")
-    # the two tables depend on the parameters only (embedding table, W_1): built once per (emb, W_1, T) version
-    ck = (emb.data_ptr(), emb._version, w1.data_ptr(), w1._version, T, tuple(emb.shape), bf16)
-    hit = _p_table_cache.get(ck)
-    if hit is None:
-        if len(_p_table_cache) > 4:
-            _p_table_cache.clear()
-        w1f, embf = _ops._c(w1, torch.float32), _ops._c(emb, torch.float32)
-        # P [n_graph, 32] fp32 (for bf16 inputs: the fp32 product of the bf16 values), W_1's tag rows; keeps the key tensors alive
-        hit = _p_table_cache[ck] = (_ops.linear(embf, w1f[T:], w_is_km=True), w1f[:T].contiguous(), emb, w1)
-    p_table, w1_tag = hit[0], hit[1]
+    p_table, w1_tag, bf16 = _h1_tables(T, emb, w1)
     off = batch.node_off()
     total = batch.total()
     h1 = torch.empty((total, 32), dtype=torch.bfloat16 if bf16 else torch.float32, device=emb.device)
@@ -538,6 +543,50 @@ def graph_conv_stack(g, d_inv, x, weights, batch=None, h1=None, head_k1=None):
     return cat, z[:, 0]
 
 
+def score_stack(batch, tag_map, tags_size, emb, weights, head_k1, pool_k=None, fuse_tables=True):
+    """The scoring form of the conv stack with both ends fused (lpg_seal_score_stack_f32 / _bf16):
+    layer 1 gathered from the two tables in the kernel's prologue (H_1 never touches HBM), layers 1..4 + the head's
+    conv1d #1 as graph_conv_stack(head_k1=...), and -- with pool_k -- SortPooling in the epilogue.
+    Returns pooled [B, pool_k * 16] (pool_k given) or (a16 [total, 16], key [total]).  Needs the reference's layer
+    widths (32 / 32 / 32 / 1), fp32 or bf16 storage."""
+    lib = _lib.load()
+    dt = weights[0].dtype
+    if not _dense_ok(weights, dt) or emb.dtype != dt:
+        raise ValueError("score_stack: needs the reference's architecture (widths 32/32/32/1), emb and weights of one dtype")
+    T = int(tags_size)
+    bf16 = dt == torch.bfloat16
+    k1 = _ops._c(head_k1, torch.float32)
+    if tuple(k1.shape) != (96, 16):
+        raise ValueError("score_stack: head_k1 must be [96, 16]")
+    dev = batch.n.device
+    off, total = batch.node_off(), batch.total()
+    n_win = -(-total // CONV_WINDOW)
+    if batch._first is not None:
+        first = batch._first
+    else:
+        first = torch.empty(n_win + 1, dtype=torch.int32, device=dev)
+        _lib.check(lib.lpg_seal_conv_windows(_ops._ptr(off), batch.B, n_win, CONV_WINDOW, _ops._ptr(first), _ops._stream()),
+                   "seal_conv_windows")
+    P = _ops._ptr
+    h1 = None
+    p_table, w1_tag, _ = _h1_tables(T, emb, weights[0])
+    if not fuse_tables:
+        h1 = first_layer_h1(batch, tag_map, T, emb, weights[0], check=False)
+    pooled = key = a16 = None
+    if pool_k is not None:
+        pooled = torch.empty((batch.B, int(pool_k) * 16), dtype=torch.float32, device=dev)
+    else:
+        key = torch.empty(total, dtype=torch.float32, device=dev)
+        a16 = torch.empty((total, 16), dtype=torch.float32, device=dev)
+    w2, w3, w4 = (_ops._c(w, dt) for w in weights[1:])
+    fn = lib.lpg_seal_score_stack_bf16 if bf16 else lib.lpg_seal_score_stack_f32
+    _lib.check(fn(P(off), P(first), n_win, P(batch.adj_bits), P(h1), 32 if h1 is None else h1.stride(0), P(batch.nodes),
+                  P(batch.tags), P(tag_map), 0 if tag_map is None else tag_map.numel(), T, P(w1_tag), P(p_table), emb.shape[0],
+                  P(w2), P(w3), P(w4), P(k1), P(key), P(a16), P(pooled), 0 if pool_k is None else int(pool_k),
+                  P(_ops.err_flag(dev)), _ops._stream()), "seal_score_stack")
+    return pooled if pool_k is not None else (a16, key)
+
+
 def sortpool(z, key, node_off, k):
     """SortPooling (SEAL/model/gnn.py:82-91): [B, k, C], rows ordered by key descending."""
     lib = _lib.load()
@@ -575,7 +624,7 @@ def _folded_conv2_dense(hw, k):
     return out
 
 
-def head(z, key, node_off, hw, a_all=None, check=True):
+def head(z, key, node_off, hw, a_all=None, check=True, pooled=None):
     """The DGCNN head of SEAL/model/gnn.py:82-137, batched over all subgraphs:
     SortPooling -> conv1d(96->16, stride 96) -> conv1d(width 5, 16->32) -> dense 128 relu -> dense 2
     -> softmax.  Every stage is one launch on the whole batch.  Neither convolution has an activation: conv1d #1
@@ -584,7 +633,7 @@ def head(z, key, node_off, hw, a_all=None, check=True):
     hw: dict with conv1d_kernel_1 [96,1,16], conv1d_kernel_2 [5,16,32], weight_1 [448,128], bias_1,
     weight_2 [128,2], bias_2 (the shipped checkpoint's tensors).  Returns (pre_y [B,2], score [B]).
     a_all: z @ conv1d_kernel_1 [total, 16] when the conv stack already produced it (graph_conv_stack(head_k1=));
-    z may then be None.  check=False: the forward's deferred index check (one host sync) is left to the caller --
+    z may then be None.  pooled: [B, k * 16] when the stack also pooled (score_stack(pool_k=k)); z, key, a_all unused.  check=False: the forward's deferred index check (one host sync) is left to the caller --
     ops.raise_if_flagged(device) after a scoring loop -- so consecutive forwards queue up without a gap."""
     lib = _lib.load()
     k1 = hw["conv1d_kernel_1"].reshape(-1, hw["conv1d_kernel_1"].shape[-1])          # [96, 16]
@@ -594,9 +643,12 @@ def head(z, key, node_off, hw, a_all=None, check=True):
     # conv1d #1 is a per-vertex linear (stride = filter width = one 96-wide row) with no activation, and SortPooling
     # only gathers rows (zero rows stay zero): conv1d(sortpool(z)) == sortpool(z @ k1) value for value.  Multiplying
     # first moves 16-float rows through the pooling instead of 96-float ones (1.25 GB less traffic per 100 K subgraphs).
-    if a_all is None:
-        a_all = _ops.linear(z, k1, w_is_km=True)
-    a = sortpool(a_all, key, node_off, k).view(B, k * c1)                                # [B, k*16]
+    if pooled is not None:                                                               # pooled by the conv stack's epilogue
+        a = pooled.view(B, k * c1)
+    else:
+        if a_all is None:
+            a_all = _ops.linear(z, k1, w_is_km=True)
+        a = sortpool(a_all, key, node_off, k).view(B, k * c1)                            # [B, k*16]
     # conv1d #2 (width 5, stride 1, VALID) has NO activation and neither has the flatten: conv1d #2 followed by the
     # dense layer is ONE linear map from the pooled [k, 16] block to the 128 dense units.  Its matrix is folded once
     # per set of weights; the [B*k, 32] convolution output (230 MB per 100 K subgraphs) is never formed.
@@ -625,6 +677,13 @@ def score_links(positive, negative, nodes_size, emb, weights, head_weights, test
         k1 = head_weights["conv1d_kernel_1"]
         k1 = k1.reshape(-1, k1.shape[-1])
         fuse = tuple(k1.shape) == (96, 16) and _lib.get_option("seal_conv_fp32") == 0
+        if fuse and _lib.get_option("seal_conv_variant") == 0:
+            # tags / nodes in, pooled rows out: one launch between the extraction and the dense layers
+            fw, c1, c2 = head_weights["conv1d_kernel_2"].shape
+            pool_k = head_weights["weight_1"].shape[0] // c2 + fw - 1
+            pooled = score_stack(batch, tag_map, T, emb, weights, k1, pool_k=pool_k)
+            _, score = head(None, None, batch.node_off(), head_weights, pooled=pooled)
+            return score, labels, batch
         h1 = first_layer_h1(batch, tag_map, T, emb, weights[0], check=False)       # head() reads the flag at the end
         z, key = graph_conv_stack(None, None, None, weights, batch=batch, h1=h1, head_k1=k1 if fuse else None)
         _, score = head(None if fuse else z, key, batch.node_off(), head_weights, a_all=z if fuse else None)

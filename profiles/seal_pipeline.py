@@ -25,9 +25,8 @@ for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
     gw, e = [w.to(dt) for w in gw32], emb.to(dt)
     def fwd():
         batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0)
-        h1 = seal.first_layer_h1(batch, tag_map, T, e, gw[0], check=False)
-        a16, key = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1)
-        return seal.head(None, key, batch.node_off(), hw, a_all=a16, check=False)[1]
+        pooled = seal.score_stack(batch, tag_map, T, e, gw, k1, pool_k=k)
+        return seal.head(None, None, batch.node_off(), hw, pooled=pooled, check=False)[1]
     for _ in range(3): fwd()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): s = fwd()

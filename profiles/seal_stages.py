@@ -43,6 +43,11 @@ for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
     tot = t_ext + t_h1 + t_conv + t_head
     print(f"{name}: first_layer_h1 {t_h1:.3f}  dense stack + conv1d #1 {t_conv:.3f} (writing the concat instead: {t_cat:.3f})  head {t_head:.3f} ms"
           f"  => extract + h1 + stack + head = {tot:.3f} ms = {B / tot / 1e3:.1f} M scored edges/s")
+    t_fused, pooled = T(lambda: seal.score_stack(batch, tag_map, Tn, e, gw, k1, pool_k=k))
+    t_head2, _ = T(lambda: seal.head(None, None, batch.node_off(), hw, pooled=pooled))
+    tot2 = t_ext + t_fused + t_head2
+    print(f"{name} fused ends: tables + stack + conv1d #1 + SortPooling {t_fused:.3f}  dense layers {t_head2:.3f} ms"
+          f"  => extract + stack + head = {tot2:.3f} ms = {B / tot2 / 1e3:.1f} M scored edges/s")
     if "--generic" in sys.argv:
         t_in, (g, d_inv, x) = T(lambda: seal.gnn_inputs(batch, tag_map, Tn, e.float(), dtype=dt))
         t_gen, _ = T(lambda: seal.graph_conv_stack(g, d_inv, x, gw))

@@ -1409,6 +1409,17 @@ def test_seal_head_with_reference_weights(dev, sl, golden_dir):
         by = 4 * TOL * agg.seal_head_mag(zz[off[gi]:off[gi + 1]], kk[off[gi]:off[gi + 1]], hw_np)
         assert abs(sc2[gi] - want_s) <= by.sum() / 4 + 1e-7
     assert float((s2 - score).abs().max()) <= 1e-5
+    # the scoring stack with both ends fused (layer 1 from the tables in the prologue, SortPooling in the epilogue) against
+    # the same stack launch by launch: bit for bit, for every combination of the two fusions
+    k1m = hw["conv1d_kernel_1"].reshape(96, 16)
+    a16_ref, key_ref = seal.graph_conv_stack(None, None, None, gw, batch=batch, h1=h1, head_k1=k1m)
+    pooled_ref = seal.sortpool(a16_ref, key_ref, batch.node_off(), 18).view(batch.B, -1)
+    a16_f, key_f = seal.score_stack(batch, tag_map, T, emb, gw, k1m)
+    assert torch.equal(a16_f, a16_ref) and torch.equal(key_f, key_ref)
+    for fuse_tables in (True, False):
+        pooled = seal.score_stack(batch, tag_map, T, emb, gw, k1m, pool_k=18, fuse_tables=fuse_tables)
+        assert pooled.shape == (batch.B, 18 * 16) and torch.equal(pooled, pooled_ref)
+    assert torch.equal(seal.head(None, None, batch.node_off(), hw, pooled=pooled)[1], s2)
     y = _np(lab).reshape(-1)
     assert 0.0 <= agg.auc(y, _np(s2)) <= 1.0
     # edge file -> scores (SEAL/config/data.py:10-32 + the forward): the loader reproduces the golden candidates, so
@@ -1926,6 +1937,13 @@ def test_config2_collab_seal_bf16_d128(dev):
     assert a16.dtype == torch.float32 and kf.dtype == torch.float32 and torch.equal(kf.to(torch.bfloat16), k16)
     want, mag = z16.double() @ k1.double(), z16.double().abs() @ k1.double().abs()
     assert torch.all((a16.double() - want).abs() <= TOL * mag + 1e-30)
+    # both ends fused (tables in the prologue, SortPooling in the epilogue): bit for bit the launch-by-launch result,
+    # incl. subgraphs of 2 vertices (zero-padded) and of 100 (truncated to 18 rows)
+    pooled_ref = seal.sortpool(a16, kf, batch.node_off(), 18).view(B, -1)
+    a16_f, key_f = seal.score_stack(batch, tag_map, T, emb16, w16, k1)
+    assert torch.equal(a16_f, a16) and torch.equal(key_f, kf)
+    for fuse_tables in (True, False):
+        assert torch.equal(seal.score_stack(batch, tag_map, T, emb16, w16, k1, pool_k=18, fuse_tables=fuse_tables), pooled_ref)
     # head (fp32 arithmetic on the bf16 activations), random-init weights of the reference's DGCNN shapes (k = 18)
     hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, generator=gen, device=dev) * 0.1,
           "conv1d_kernel_2": torch.randn(5, 16, 32, generator=gen, device=dev) * 0.1,
