@@ -439,21 +439,24 @@ int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* first, int6
  *  - pooled != NULL: SortPooling (SEAL/model/gnn.py:82-91; the total order of lpg_seal_sortpool_f32) of the 16-wide
  *    rows runs in the epilogue and the kernel writes pooled [B, pool_k, 16]; key / head_a16 may then be NULL.
  * Either fusion can be left out (h1 given / pooled NULL: key and head_a16 are written as by lpg_seal_conv_stack_*).
+ * n_windows == -1: the number of row windows is ceil(node_off[n_subgraphs] / 128), read ON THE DEVICE (first from
+ * lpg_seal_conv_windows(n_windows = -1), n_subgraphs + 2 entries): with pooled output nothing between the
+ * extraction and the scores needs the batch's vertex total on the host -- no sync in a scoring forward.
  * err_flag: OR-ed with LPG_F_INDEX_RANGE when a tag or node of a row is out of range (the row is then zero). */
 int lpg_seal_score_stack_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows,
                              const uint32_t* adj_bits, const float* h1, int64_t ldh, const int32_t* nodes,
                              const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len, int64_t T,
                              const float* w1_tag, const float* p_table, int64_t n_graph, const float* w2,
                              const float* w3, const float* w4, const float* head_k1, float* key,
-                             float* head_a16, float* pooled, int64_t pool_k, int32_t* err_flag,
-                             void* stream);
+                             float* head_a16, float* pooled, int64_t pool_k, int64_t n_subgraphs,
+                             int32_t* err_flag, void* stream);
 int lpg_seal_score_stack_bf16(const int64_t* node_off, const int32_t* first, int64_t n_windows,
                               const uint32_t* adj_bits, const uint16_t* h1, int64_t ldh,
                               const int32_t* nodes, const int32_t* tags, const int32_t* tag_map,
                               int64_t tag_map_len, int64_t T, const float* w1_tag, const float* p_table,
                               int64_t n_graph, const uint16_t* w2, const uint16_t* w3, const uint16_t* w4,
                               const float* head_k1, float* key, float* head_a16, float* pooled,
-                              int64_t pool_k, int32_t* err_flag, void* stream);
+                              int64_t pool_k, int64_t n_subgraphs, int32_t* err_flag, void* stream);
 
 /* The DGCNN head's last dense layer and its softmax in one launch (SEAL/model/gnn.py:127-137): pre_y [B, 2] =
  * h [B, H] @ w [H, 2] + bias [2] (w as TensorFlow stores it, input index major), score [B] = softmax(pre_y)[:, 1]. */

@@ -490,6 +490,7 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t_kernel(
 __global__ __launch_bounds__(kConvBlock) void seal_windows_kernel(const int64_t* __restrict__ node_off, int64_t B,
                                                                   int64_t n_first, int64_t win, int32_t* __restrict__ first) {
   const int64_t w = static_cast<int64_t>(blockIdx.x) * kConvBlock + threadIdx.x;
+  if (n_first < 0) n_first = (node_off[B] + win - 1) / win + 1;     // the number of windows is read on the device
   if (w >= n_first) return;
   const int64_t target = w * win;
   int64_t lo = 0, hi = B + 1;                       // node_off has B + 1 entries
@@ -503,11 +504,13 @@ __global__ __launch_bounds__(kConvBlock) void seal_windows_kernel(const int64_t*
 
 LPG_EXPORT int lpg_seal_conv_windows(const int64_t* node_off, int64_t B, int64_t n_windows, int64_t window_rows,
                                      int32_t* first, void* stream) {
-  LPG_REQUIRE(B >= 0 && n_windows >= 0 && window_rows >= 1 && window_rows <= WIN && B < (int64_t(1) << 31),
+  LPG_REQUIRE(B >= 0 && n_windows >= -1 && window_rows >= 1 && window_rows <= WIN && B < (int64_t(1) << 31),
               "seal_conv_windows: bad sizes (window_rows <= %d)", WIN);
   LPG_REQUIRE(node_off && first, "seal_conv_windows: null pointer");
-  const int64_t n_first = n_windows + 1;
-  hipLaunchKernelGGL(seal_windows_kernel, dim3(static_cast<unsigned>(ceil_div(n_first, kConvBlock))), dim3(kConvBlock), 0,
+  // n_windows == -1: ceil(node_off[B] / window_rows), read on the device; `first` then needs B * 128 / window_rows + 2 entries
+  const int64_t n_first = n_windows >= 0 ? n_windows + 1 : -1;
+  const int64_t threads = n_windows >= 0 ? n_first : B * (WIN / window_rows) * (MAXN / WIN) + 2;
+  hipLaunchKernelGGL(seal_windows_kernel, dim3(static_cast<unsigned>(ceil_div(threads, kConvBlock))), dim3(kConvBlock), 0,
                      as_stream(stream), node_off, B, n_first, window_rows, first);
   return check_launch("seal_conv_windows");
 }

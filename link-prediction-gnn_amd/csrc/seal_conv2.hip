@@ -110,11 +110,15 @@ struct RowCtxT {
 };
 
 template <int NP, typename TIN, bool CAT>
-__global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
+__global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_conv_t2_kernel(
     const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
     const TIN* __restrict__ h1, int64_t ldh, const TIN* __restrict__ w2, const TIN* __restrict__ w3,
     const TIN* __restrict__ w4, TIN* __restrict__ cat, int64_t ldc, float* __restrict__ key,
-    const float* __restrict__ k1, float* __restrict__ a16, const ConvFuse fx) {
+    const float* __restrict__ k1, float* __restrict__ a16, const ConvFuse fx, int64_t n_windows,
+    const int64_t* __restrict__ total_ptr) {
+  // Windows are walked with a grid stride: n_windows of them, or -- total_ptr given (the batch's vertex total, still on
+  // the device) -- ceil(*total_ptr / 128), so that the host never has to read the total to size this launch.  The weight
+  // fragments are staged once per workgroup, not once per window.
   __shared__ __attribute__((aligned(16))) uint16_t Hp[NP][32][HS];     // H^T as NP bf16 planes
   __shared__ __attribute__((aligned(16))) uint4 lut[256];             // byte -> 8 x bf16 {0, 1}
   __shared__ __attribute__((aligned(16))) uint4 Wb[2][NP][2][64];     // W_2, W_3: A fragments [layer][plane][k step][lane]
@@ -125,54 +129,9 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
   __shared__ int32_t rnode[RMAX];                   // tables mode: the row's graph node (-1: invalid) ...
   __shared__ uint16_t rtag[RMAX];                   // ... and its column in the one-hot block
   __shared__ __attribute__((aligned(16))) float zt[CAT ? kConvBlock / 64 : 1][CAT ? 16 : 1][36];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int bf = first[blockIdx.x], bl = first[blockIdx.x + 1];
-  if (bl <= bf) return;
-  const int nsub = bl - bf;
-  const int64_t r_lo = node_off[bf];
-  const int nrows = static_cast<int>(node_off[bl] - r_lo);
-  const int ntiles = (nrows + 31) >> 5;             // <= 8
-
-  // ---- H_1 planes: a wave-sized group of items covers 16 row pairs x 4 feature quads (half a 32-row tile, half the
-  // features): lane (i = l & 15, q = l >> 4) takes the 16-byte pieces [4 kq, 4 kq + 4) of rows 2 rp and 2 rp + 1 and
-  // writes 12 (or 4) row-pair dwords; dword index = feature * 132 + rp, so the 64 lanes of a write hit 64 banks.
-  // `piece(row, kq, v)` yields the four values: a 16-byte read of h1, or (tables mode, after the row table below) the
-  // sum of two 16-byte gathers.
-  auto fill_planes = [&](auto piece) {
-    for (int idx = tid; idx < ntiles * 128; idx += kConvBlock) {
-      const int g = idx >> 6, l = idx & 63;
-      const int rp = (g >> 1) * 16 + (l & 15), kq = (g & 1) * 4 + (l >> 4), row = 2 * rp;
-      float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};   // rows past the end are zero (0 x NaN is not)
-      if (row < nrows) piece(row, kq, v0);
-      if (row + 1 < nrows) piece(row + 1, kq, v1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint32_t a[NP], b[NP];
-        planes_of<NP>(v0[j], a);
-        planes_of<NP>(v1[j], b);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kq + j][row]) = a[p] | (b[p] << 16);
-      }
-    }
-  };
-  if (h1)
-    fill_planes([&](int row, int kq, float (&v)[4]) {
-      if constexpr (sizeof(TIN) == 4) {
-        const float4 q = *reinterpret_cast<const float4*>(h1 + (r_lo + row) * ldh + 4 * kq);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-      } else {
-        const uint2 q = *reinterpret_cast<const uint2*>(h1 + (r_lo + row) * ldh + 4 * kq);
-        v[0] = bf16_to_f32(q.x & 0xFFFFu); v[1] = bf16_to_f32(q.x >> 16); v[2] = bf16_to_f32(q.y & 0xFFFFu); v[3] = bf16_to_f32(q.y >> 16);
-      }
-    });
-  {                                                 // byte -> 8 bf16 (bit j set -> 1.0 = 0x3F80 in element j)
-    uint32_t d[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      d[q] = (((tid >> (2 * q)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * q + 1)) & 1) ? 0x3F800000u : 0u);
-    lut[tid] = make_uint4(d[0], d[1], d[2], d[3]);
-  }
+  // ---- once per workgroup: the weight operands
+  {
+  const int tid = threadIdx.x;
   // W_l[f][o] -> the A fragment of lane (o = ln & 31, hh = ln >> 5) for k step s2: f = acc_row(8 s2 + j, hh), j = 0..7
   {
     const int l = tid >> 7, s2 = (tid >> 6) & 1, ln = tid & 63;       // 2 x 2 x 64 = 256 fragments: one per thread
@@ -222,6 +181,63 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) W4b[p][s2][hh] = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
+  }
+  }
+  const int64_t nwin = total_ptr ? (total_ptr[0] + WIN - 1) / WIN : n_windows;
+  for (int64_t win_id = blockIdx.x; win_id < nwin; win_id += gridDim.x) {
+  __syncthreads();                                  // the previous window's last readers of the planes / tables are done
+  // the thread's coordinates are re-derived per window behind an opaque zero: with loop-invariant lane arithmetic the
+  // compiler hoisted every LDS / global address of the body out of the window loop and kept ~70 more VGPRs live
+  // (186 -> 250, the bf16 kernel lost its third wave per SIMD)
+  int opaque0;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+  const int tid = static_cast<int>(threadIdx.x) + opaque0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int bf = first[win_id], bl = first[win_id + 1];
+  if (bl <= bf) continue;                           // a window inside one big subgraph owns nothing (block-uniform)
+  const int nsub = bl - bf;
+  const int64_t r_lo = node_off[bf];
+  const int nrows = static_cast<int>(node_off[bl] - r_lo);
+  const int ntiles = (nrows + 31) >> 5;             // <= 8
+
+  // ---- H_1 planes: a wave-sized group of items covers 16 row pairs x 4 feature quads (half a 32-row tile, half the
+  // features): lane (i = l & 15, q = l >> 4) takes the 16-byte pieces [4 kq, 4 kq + 4) of rows 2 rp and 2 rp + 1 and
+  // writes 12 (or 4) row-pair dwords; dword index = feature * 132 + rp, so the 64 lanes of a write hit 64 banks.
+  // `piece(row, kq, v)` yields the four values: a 16-byte read of h1, or (tables mode, after the row table below) the
+  // sum of two 16-byte gathers.
+  auto fill_planes = [&](auto piece) {
+    for (int idx = tid; idx < ntiles * 128; idx += kConvBlock) {
+      const int g = idx >> 6, l = idx & 63;
+      const int rp = (g >> 1) * 16 + (l & 15), kq = (g & 1) * 4 + (l >> 4), row = 2 * rp;
+      float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};   // rows past the end are zero (0 x NaN is not)
+      if (row < nrows) piece(row, kq, v0);
+      if (row + 1 < nrows) piece(row + 1, kq, v1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t a[NP], b[NP];
+        planes_of<NP>(v0[j], a);
+        planes_of<NP>(v1[j], b);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kq + j][row]) = a[p] | (b[p] << 16);
+      }
+    }
+  };
+  if (h1)
+    fill_planes([&](int row, int kq, float (&v)[4]) {
+      if constexpr (sizeof(TIN) == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(h1 + (r_lo + row) * ldh + 4 * kq);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+        const uint2 q = *reinterpret_cast<const uint2*>(h1 + (r_lo + row) * ldh + 4 * kq);
+        v[0] = bf16_to_f32(q.x & 0xFFFFu); v[1] = bf16_to_f32(q.x >> 16); v[2] = bf16_to_f32(q.y & 0xFFFFu); v[3] = bf16_to_f32(q.y >> 16);
+      }
+    });
+  {                                                 // byte -> 8 bf16 (bit j set -> 1.0 = 0x3F80 in element j)
+    uint32_t d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      d[q] = (((tid >> (2 * q)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * q + 1)) & 1) ? 0x3F800000u : 0u);
+    lut[tid] = make_uint4(d[0], d[1], d[2], d[3]);
   }
   // ---- per-subgraph offsets, per-row (subgraph, vertex)
   for (int q = tid; q <= nsub; q += kConvBlock) soff[q] = static_cast<int>(node_off[bf + q] - r_lo);
@@ -513,19 +529,40 @@ __global__ __launch_bounds__(kConvBlock, 2) void seal_conv_t2_kernel(
         reinterpret_cast<float4*>(fx.pooled + (static_cast<int64_t>(bf + q) * pk + rr) * 16)[rem & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  }   // windows
+}
+
+// workgroups of `kernel` the chip holds at once (occupancy x CUs); 512 if the runtime cannot say
+inline int64_t resident_slots(const void* kernel) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kConvBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
+  return static_cast<int64_t>(per_cu) * prop.multiProcessorCount;
 }
 
 template <int NP, typename TIN>
 int launch_conv2(const int64_t* node_off, const int32_t* first, int64_t n_windows, const uint32_t* adj_bits, const TIN* h1,
                  int64_t ldh, const TIN* w2, const TIN* w3, const TIN* w4, TIN* cat, int64_t ldc, float* key,
-                 const float* head_k1, float* head_a16, const ConvFuse& fx, hipStream_t st) {
-  const dim3 grid(static_cast<unsigned>(n_windows)), blk(kConvBlock);
+                 const float* head_k1, float* head_a16, const ConvFuse& fx, hipStream_t st, int64_t n_subgraphs = 0) {
+  // n_windows >= 0: known on the host; < 0: ceil(node_off[n_subgraphs] / 128), read on the device (no host sync between
+  // the extraction and this launch).  Either way a bounded grid walks the windows: two workgroups fit a CU, and four
+  // per CU keep the tail short while the weight fragments are still staged ~5 times less often than once per window.
+  const int64_t upper = n_windows >= 0 ? n_windows : n_subgraphs + 1;          // a subgraph has <= 128 rows
+  // four workgroups per resident slot: the hardware dispatcher still balances windows of different cost (a grid of exactly
+  // the resident slots waits for its unluckiest member; 1.33 x the slots runs a second, mostly empty round: bf16 0.44 -> 0.64 ms)
+  static const int64_t slots_cat = resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, true>));
+  static const int64_t slots = resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, false>));
+  const int64_t cap = 4 * (cat ? slots_cat : slots);
+  const int64_t g = upper < cap ? (upper < 1 ? 1 : upper) : cap;
+  const dim3 grid(static_cast<unsigned>(g)), blk(kConvBlock);
+  const int64_t* total_ptr = n_windows >= 0 ? nullptr : node_off + n_subgraphs;
   if (cat)
     hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, true>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat,
-                       ldc, key, head_k1, head_a16, fx);
+                       ldc, key, head_k1, head_a16, fx, n_windows, total_ptr);
   else
     hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, false>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4,
-                       cat, ldc, key, head_k1, head_a16, fx);
+                       cat, ldc, key, head_k1, head_a16, fx, n_windows, total_ptr);
   return check_launch("seal_conv_stack");
 }
 
@@ -564,9 +601,10 @@ LPG_EXPORT int lpg_seal_score_stack_f32(const int64_t* node_off, const int32_t* 
                                         const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len, int64_t T,
                                         const float* w1_tag, const float* p_table, int64_t n_graph, const float* w2,
                                         const float* w3, const float* w4, const float* head_k1, float* key, float* head_a16,
-                                        float* pooled, int64_t pool_k, int32_t* err_flag, void* stream) {
-  LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && (!h1 || (ldh >= 32 && ldh % 4 == 0)), "seal_score_stack: bad sizes");
-  if (n_windows == 0) return LPG_OK;
+                                        float* pooled, int64_t pool_k, int64_t n_subgraphs, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(n_windows >= -1 && n_windows < (int64_t(1) << 31) && n_subgraphs >= 0 && n_subgraphs < (int64_t(1) << 31) &&
+              (!h1 || (ldh >= 32 && ldh % 4 == 0)), "seal_score_stack: bad sizes");
+  if (n_windows == 0 || (n_windows < 0 && n_subgraphs == 0)) return LPG_OK;
   LPG_REQUIRE(node_off && first && adj_bits && w2 && w3 && w4, "seal_score_stack: null pointer");
   LPG_REQUIRE((!h1 || reinterpret_cast<uintptr_t>(h1) % 16 == 0) && (!head_a16 || reinterpret_cast<uintptr_t>(head_a16) % 16 == 0),
               "seal_score_stack: h1 / head_a16 must be 16-byte aligned");
@@ -575,7 +613,7 @@ LPG_EXPORT int lpg_seal_score_stack_f32(const int64_t* node_off, const int32_t* 
                          key, head_a16, nullptr, err_flag)) return rc;
   LPG_REQUIRE(head_k1, "seal_score_stack: head_k1 is required (the concat form is lpg_seal_conv_stack_f32)");
   return launch_conv2<3, float>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, nullptr, 96, key, head_k1, head_a16, fx,
-                                as_stream(stream));
+                                as_stream(stream), n_subgraphs);
 }
 
 LPG_EXPORT int lpg_seal_score_stack_bf16(const int64_t* node_off, const int32_t* first, int64_t n_windows,
@@ -583,9 +621,11 @@ LPG_EXPORT int lpg_seal_score_stack_bf16(const int64_t* node_off, const int32_t*
                                          const int32_t* tags, const int32_t* tag_map, int64_t tag_map_len, int64_t T,
                                          const float* w1_tag, const float* p_table, int64_t n_graph, const uint16_t* w2,
                                          const uint16_t* w3, const uint16_t* w4, const float* head_k1, float* key,
-                                         float* head_a16, float* pooled, int64_t pool_k, int32_t* err_flag, void* stream) {
-  LPG_REQUIRE(n_windows >= 0 && n_windows < (int64_t(1) << 31) && (!h1 || (ldh >= 32 && ldh % 4 == 0)), "seal_score_stack_bf16: bad sizes");
-  if (n_windows == 0) return LPG_OK;
+                                         float* head_a16, float* pooled, int64_t pool_k, int64_t n_subgraphs, int32_t* err_flag,
+                                         void* stream) {
+  LPG_REQUIRE(n_windows >= -1 && n_windows < (int64_t(1) << 31) && n_subgraphs >= 0 && n_subgraphs < (int64_t(1) << 31) &&
+              (!h1 || (ldh >= 32 && ldh % 4 == 0)), "seal_score_stack_bf16: bad sizes");
+  if (n_windows == 0 || (n_windows < 0 && n_subgraphs == 0)) return LPG_OK;
   LPG_REQUIRE(node_off && first && adj_bits && w2 && w3 && w4, "seal_score_stack_bf16: null pointer");
   LPG_REQUIRE((!h1 || reinterpret_cast<uintptr_t>(h1) % 8 == 0) && (!head_a16 || reinterpret_cast<uintptr_t>(head_a16) % 16 == 0),
               "seal_score_stack_bf16: h1 must be 8-byte, head_a16 16-byte aligned");
@@ -594,7 +634,7 @@ LPG_EXPORT int lpg_seal_score_stack_bf16(const int64_t* node_off, const int32_t*
                          key, head_a16, nullptr, err_flag)) return rc;
   LPG_REQUIRE(head_k1, "seal_score_stack_bf16: head_k1 is required (the concat form is lpg_seal_conv_stack_bf16)");
   return launch_conv2<1, uint16_t>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, nullptr, 96, key, head_k1, head_a16, fx,
-                                   as_stream(stream));
+                                   as_stream(stream), n_subgraphs);
 }
 
 LPG_EXPORT int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* first, int64_t n_windows,

@@ -559,12 +559,17 @@ def score_stack(batch, tag_map, tags_size, emb, weights, head_k1, pool_k=None, f
     if tuple(k1.shape) != (96, 16):
         raise ValueError("score_stack: head_k1 must be [96, 16]")
     dev = batch.n.device
-    off, total = batch.node_off(), batch.total()
-    n_win = -(-total // CONV_WINDOW)
+    off = batch.node_off()
+    # With pooled output nothing below needs the batch's vertex total on the HOST: the kernel reads the number of row
+    # windows from node_off[B] on the device (n_windows = -1) and walks them with a bounded grid -- no sync between the
+    # extraction and the scores.  (a16 / key outputs are sized by the total: that form reads it.)
+    device_count = pool_k is not None and fuse_tables
+    total = None if device_count else batch.total()
+    n_win = -1 if device_count else -(-total // CONV_WINDOW)
     if batch._first is not None:
         first = batch._first
     else:
-        first = torch.empty(n_win + 1, dtype=torch.int32, device=dev)
+        first = torch.empty((batch.B + 2) if device_count else (n_win + 1), dtype=torch.int32, device=dev)
         _lib.check(lib.lpg_seal_conv_windows(_ops._ptr(off), batch.B, n_win, CONV_WINDOW, _ops._ptr(first), _ops._stream()),
                    "seal_conv_windows")
     P = _ops._ptr
@@ -582,7 +587,7 @@ def score_stack(batch, tag_map, tags_size, emb, weights, head_k1, pool_k=None, f
     fn = lib.lpg_seal_score_stack_bf16 if bf16 else lib.lpg_seal_score_stack_f32
     _lib.check(fn(P(off), P(first), n_win, P(batch.adj_bits), P(h1), 32 if h1 is None else h1.stride(0), P(batch.nodes),
                   P(batch.tags), P(tag_map), 0 if tag_map is None else tag_map.numel(), T, P(w1_tag), P(p_table), emb.shape[0],
-                  P(w2), P(w3), P(w4), P(k1), P(key), P(a16), P(pooled), 0 if pool_k is None else int(pool_k),
+                  P(w2), P(w3), P(w4), P(k1), P(key), P(a16), P(pooled), 0 if pool_k is None else int(pool_k), batch.B,
                   P(_ops.err_flag(dev)), _ops._stream()), "seal_score_stack")
     return pooled if pool_k is not None else (a16, key)
 
