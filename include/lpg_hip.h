@@ -48,7 +48,8 @@ int lpg_abi_version(void);
  * the environment at all.  Every value a release build accepts selects between variants that all return correct
  * results (the tests pin each to the oracle): "spmm_chunk", "spmm_mode" (0 / 1), "spmm_lds", "spmm_block",
  * "spmm_off32", "spmm_rows_max", "spmm_rows_ecap", "spmm_no_edge", "seal_conv_fp32", "gn_small",
- * "seal_conv_variant", "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant), "seal_pair_small",
+ * "seal_conv_variant", "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant),
+ * "linear_x3" (-1 automatic, 0 off, 1 force: the fp32 linear as exact three-plane bf16 products, csrc/linear_x3.hip), "seal_pair_small",
  * "spmm_phase_timing" (1: lpg_csr_spmm_* record events around their kernels, see lpg_csr_spmm_phase_ms).
  * `name` is a HOST string.  set: 0 / LPG_E_INVALID (unknown name, value out of range); get: the value, INT64_MIN
  * for an unknown name.  lpg_tuning_build() = 1 for a -DLPG_TUNING build (profiles/ sweeps only: seeds the table

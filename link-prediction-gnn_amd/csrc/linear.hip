@@ -268,6 +268,11 @@ LPG_EXPORT int lpg_linear_f32(const float* x, int64_t ldx, const float* w, int w
   LPG_REQUIRE(x && w && y, "linear: null pointer");
   hipStream_t st = as_stream(stream);
   {
+    const int r = linear_x3_f32(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
+    if (r < 0) return r;
+    if (r > 0) return check_launch("linear (bf16 planes)");
+  }
+  {
     const int r = linear_wres_f32(x, ldx, w, w_is_km, bias, act, y, ldy, n, k, m, st);
     if (r < 0) return r;
     if (r > 0) return check_launch("linear (W-resident)");

@@ -36,6 +36,8 @@ struct Options {
   int64_t linear_wres = -1;      // -1 automatic; 0 off; 1 / 2 / 3 force that W-resident variant (also below n_min)
   int64_t spmm_phase_timing = 0; // 1: record events around the SpMM's kernels (lpg_csr_spmm_phase_ms)
   int64_t seal_pair_small = 1;   // 0: every candidate pair takes the 128-thread extraction workgroup
+  int64_t linear_x3 = -1;        // -1 automatic; 0 off; 1 force: fp32 linear as exact bf16 plane products on the bf16 matrix cores (linear_x3.hip)
+  int64_t stat_linear_x3 = 0;    // statistic: launches of that kernel so far
   int64_t stat_linear_wres = 0;  // statistic: W-resident linear launches so far (tests assert the path taken; set 0 to reset)
 };
 const Options& options();
@@ -86,6 +88,10 @@ int linear_wres_f32(const float* x, int64_t ldx, const float* w, int w_is_km, co
                     int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st);
 int linear_wres_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, int w_is_km, const float* bias, int act,
                      uint16_t* y, int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st);
+
+// linear_x3.hip: fp32 linear on the bf16 matrix cores through the exact three-plane split; same return convention
+int linear_x3_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, int act, float* y,
+                  int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st);
 
 // seal_conv2.hip: the SEAL conv stack with every product on the bf16 matrix cores (fp32-class plane arithmetic)
 int seal_conv2_f32(const int64_t* node_off, const int32_t* first, int64_t n_windows, const uint32_t* adj_bits,

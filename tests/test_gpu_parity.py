@@ -1623,6 +1623,64 @@ def test_linear_bf16_mfma(dev, n, k, m, km):
     assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + TOL * mag + 1e-30)
 
 
+@pytest.mark.parametrize("n,k,m,ldx,km,act,bias,w_off", [
+    (20011, 128, 128, 128, False, None, True, 0),        # one strip, ragged last row tile
+    (50011, 128, 128, 128, False, "relu", True, 0),
+    (1000, 128, 128, 128, True, "tanh", False, 0),       # fewer row tiles than waves
+    (33, 64, 64, 64, False, None, True, 0),
+    (20011, 100, 20, 100, False, "relu", True, 0),       # k not a multiple of 32 (zeroed in registers), m < one tile
+    (20011, 36, 100, 40, True, None, True, 0),           # padded rows (NaN behind k), ragged k, m not a multiple of 16
+    (17000, 128, 200, 128, False, None, True, 0),        # two strips, the second one ragged
+    (30000, 256, 256, 256, False, "relu", True, 0),      # k m too large for one strip: 4 strips of 64 columns
+    (100000, 288, 128, 288, True, "relu", True, 0),      # the SEAL head's dense layer
+    (20000, 448, 128, 448, True, "relu", True, 0),
+    (20011, 128, 128, 128, False, None, True, 1),        # W not 16-byte aligned: scalar staging
+    (20011, 128, 64, 128, True, None, False, 3),
+])
+def test_linear_f32_on_bf16_planes(dev, lpg_options, n, k, m, ldx, km, act, bias, w_off):
+    """the fp32 linear as exact three-plane bf16 products on the bf16 matrix cores (csrc/linear_x3.hip), forced for
+    every shape the layout allows, against an fp64 matmul: the dropped plane pairs are <= 3 * 2^-24 |x| |w| per
+    product, so the bound is the fp32 one (1e-5 of sum |x w|; measured 2e-7).  NaN in row padding must not leak, and
+    nothing outside [n, m] may be written.  The launch statistic proves the kernel ran."""
+    from lpgnn_amd import _lib, ops
+    lpg_options(linear_x3=1, stat_linear_x3=0)
+    rng = np.random.default_rng(n + k + m)
+    xb = torch.from_numpy(rng.standard_normal((n, ldx)).astype(np.float32)).to(dev)
+    # values across the exponent range, exact powers of two and numbers with all 24 significant bits set
+    xb[:7, :k] = torch.tensor([1.0, -2.0 ** -20, 16777215.0, -1.9999999, 3.0e-30, 2.0 ** 40, 0.0], device=dev)[:, None]
+    if ldx > k:
+        xb[:, k:] = float("nan")
+    xt = xb[:, :k]
+    wshape = (k, m) if km else (m, k)
+    wflat = torch.from_numpy(rng.standard_normal(wshape[0] * wshape[1] + w_off).astype(np.float32)).to(dev)
+    wt = wflat[w_off:].view(wshape)
+    b = rng.standard_normal(m).astype(np.float32) if bias else None
+    x64, w64 = _np(xt).astype(np.float64), _np(wt).astype(np.float64)
+    if not km:
+        w64 = w64.T
+    want = x64 @ w64 + (b if bias else 0.0)
+    mag = np.abs(x64) @ np.abs(w64) + (np.abs(b) if bias else 0.0)
+    bt = None if b is None else torch.from_numpy(b).to(dev)
+    got = ops.linear(xt, wt, bt, w_is_km=km, act=act)
+    assert _lib.get_option("stat_linear_x3") == 1, "not the kernel this test is about"
+    got = _np(got).astype(np.float64)
+    if act == "relu":
+        want = np.maximum(want, 0)
+    elif act == "tanh":
+        want = np.tanh(want)
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - want) <= TOL * (mag + 1.0))
+    wide = torch.full((n, m + 8), 7.0, device=dev)
+    ops.linear(xt, wt, bt, w_is_km=km, act=act, out=wide[:, :m])
+    assert torch.equal(wide[:, m:], torch.full((n, 8), 7.0, device=dev))
+    assert np.array_equal(_np(wide[:, :m]).astype(np.float64), got)
+    # the automatic choice takes this kernel for the matrix-core-bound shapes only, and never when it is switched off
+    lpg_options(linear_x3=0, stat_linear_x3=0)
+    off = ops.linear(xt, wt, bt, w_is_km=km, act=act)
+    assert _lib.get_option("stat_linear_x3") == 0
+    assert np.all(np.abs(_np(off).astype(np.float64) - want) <= TOL * (mag + 1.0))
+
+
 @pytest.mark.parametrize("variant", ["auto", "1", "2", "3"])
 @pytest.mark.parametrize("dtype,n,k,m,ldx,km,act,bias", [
     ("f32", 20011, 128, 128, 128, False, None, True),       # MFMA-bound shape, ragged last tile
@@ -1647,7 +1705,7 @@ def test_linear_persistent_w_resident(dev, lpg_options, variant, dtype, n, k, m,
     from lpgnn_amd import _lib, ops
     if variant != "auto":
         lpg_options(linear_wres=int(variant))              # forced variants also run below the automatic row threshold
-    lpg_options(stat_linear_wres=0)
+    lpg_options(stat_linear_wres=0, linear_x3=0)           # the bf16-plane kernel (next test) would take the MFMA-bound fp32 rows
     n_min = 49152 if (dtype == "f32" and m > 64) else 16384
     expect_wres = variant != "auto" or n >= n_min
     rng = np.random.default_rng(n + k + m)
