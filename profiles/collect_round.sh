@@ -16,6 +16,8 @@ python profiles/degree_ab.py > $OUT/degree_ab.log 2>&1
 python profiles/twowl_forward.py > $OUT/twowl_forward.log 2>&1
 python profiles/kernel_zoo.py > $OUT/kernel_zoo_after.log 2>&1
 python profiles/scatter_crossover.py > $OUT/scatter_crossover.log 2>&1
+python profiles/linear_x3.py > $OUT/linear_x3.log 2>&1
+python profiles/seal_pipeline.py > $OUT/seal_pipeline.log 2>&1
 python profiles/config_sweep.py > $OUT/config4_config5_shapes.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $ROOT/bench.py > $OUT/bench_under_rocprof.log 2>&1
