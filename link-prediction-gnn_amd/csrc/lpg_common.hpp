@@ -28,6 +28,7 @@ struct Options {
   int64_t spmm_off32 = 1;        // 32-bit gather offsets when X spans < 4 GiB
   int64_t spmm_rows_max = 32;    // longest row for which the row-parallel one-launch SpMM is taken (0 disables)
   int64_t spmm_rows_ecap = int64_t(1) << 21;
+  int64_t spmm_fill_overlap = 1; // 0: the empty-row fill of big graphs runs after the fix-up on the caller's stream instead of beside the main kernel
   int64_t spmm_no_edge = 0;      // 1: narrow features (d <= 16) stay on the main kernel
   int64_t seal_conv_fp32 = 0;    // 1: the fp32-MFMA formulation of the SEAL conv stack (no head fusion)
   int64_t seal_conv_variant = 0; // 0: every product on the bf16 matrix cores (csrc/seal_conv2.hip); 1: the r01 kernel (fp32 MFMA dense products)

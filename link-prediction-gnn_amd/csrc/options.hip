@@ -30,6 +30,7 @@ const Entry kEntries[] = {
     {"spmm_rows_max", &Options::spmm_rows_max, 0, 1 << 20},
     {"spmm_rows_ecap", &Options::spmm_rows_ecap, 0, int64_t(1) << 40},
     {"spmm_no_edge", &Options::spmm_no_edge, 0, 1},
+    {"spmm_fill_overlap", &Options::spmm_fill_overlap, 0, 1},
     {"seal_conv_fp32", &Options::seal_conv_fp32, 0, 1},
     {"seal_conv_variant", &Options::seal_conv_variant, 0, 1},
     {"gn_small", &Options::gn_small, 0, 1},

@@ -77,6 +77,39 @@ inline void phase_mark(int i, hipStream_t st) {
   if (i == 3) g_phase_recorded = true;
 }
 
+// A second stream for the empty-row fill of big graphs.  The main kernel runs one workgroup per CU (LDS reservation)
+// and is bound by the row gather at ~5.6 TB/s of the 8 TB/s the memory can move; the fill is a pure write stream to
+// rows the main and fix-up kernels never touch.  Forked before the main kernel and joined after the fix-up, about half
+// of its 0.28 ms hides behind the gather (|E| = 100 M: 9.01 -> 8.86 ms, profiles/r02/spmm_overlap_probe.log).
+// One stream + two events per host thread and device, created on first use; never inside a stream capture.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool tried = false;
+};
+SideStream* side_stream(hipStream_t st) {
+  constexpr int kMaxDev = 16;
+  thread_local SideStream side[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  SideStream& ss = side[dev];
+  if (!ss.tried) {
+    ss.tried = true;
+    if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      ss.s = nullptr;
+    }
+  }
+  return ss.s ? &ss : nullptr;
+}
+
 struct SpmmArgs {
   const int64_t* rowptr;
   const int32_t* col;
@@ -752,6 +785,30 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
     if (rc != LPG_OK) return rc;
     return check_launch("csr_spmm (rows)");
   }
+  const bool wide_out = d % WIDE == 0 && ldy % WIDE == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+  auto launch_fill = [&](hipStream_t s) {
+    if (wide_out)
+      hipLaunchKernelGGL((spmm_empty_rows_kernel<T, WIDE>), dim3(grid_for(N * (d < 64 ? d : 64) / WIDE)), dim3(kBlock), 0, s, a);
+    else
+      hipLaunchKernelGGL((spmm_empty_rows_kernel<T, 1>), dim3(grid_for(N * (d < 64 ? d : 64))), dim3(kBlock), 0, s, a);
+  };
+  // big graphs: the empty rows are filled on a second stream while the main kernel gathers (see SideStream)
+  SideStream* side = nullptr;
+  if (n_empty_hint != 0 && options().spmm_fill_overlap && e_cap >= (int64_t(1) << 24) &&
+      n_empty_hint * d * static_cast<int64_t>(sizeof(T)) >= (int64_t(64) << 20))
+    side = side_stream(st);
+  if (side) {
+    if (hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) {
+      launch_fill(side->s);
+      if (hipEventRecord(side->join, side->s) != hipSuccess) {
+        set_error("csr_spmm: cannot record the fill's completion");
+        return LPG_E_LAUNCH;
+      }
+    } else {
+      (void)hipGetLastError();
+      side = nullptr;
+    }
+  }
   phase_mark(0, st);
   phase_mark(1, st);
   // d <= 16 in a power of two: the edge-parallel kernel (lanes = edges); wider rows: lanes = feature columns
@@ -792,11 +849,14 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
     phase_mark(3, st);
     return check_launch("csr_spmm");
   }
-  const bool wide_out = d % WIDE == 0 && ldy % WIDE == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
-  if (wide_out)
-    hipLaunchKernelGGL((spmm_empty_rows_kernel<T, WIDE>), dim3(grid_for(N * (d < 64 ? d : 64) / WIDE)), dim3(kBlock), 0, st, a);
-  else
-    hipLaunchKernelGGL((spmm_empty_rows_kernel<T, 1>), dim3(grid_for(N * (d < 64 ? d : 64))), dim3(kBlock), 0, st, a);
+  if (side) {
+    if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) {
+      set_error("csr_spmm: cannot join the fill stream");
+      return LPG_E_LAUNCH;
+    }
+  } else {
+    launch_fill(st);
+  }
   phase_mark(3, st);
   return check_launch("csr_spmm");
 }

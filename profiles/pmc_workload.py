@@ -15,6 +15,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench        # noqa: E402
 import lpgnn_amd    # noqa: E402
+from lpgnn_amd import _lib    # noqa: E402
+
+_lib.set_option("spmm_fill_overlap", 0)   # the counters are per dispatch: keep main, fix-up, empty rows in that order
 
 dev = torch.device("cuda:0")
 N, d = 5_000_000, 128

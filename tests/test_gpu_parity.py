@@ -1063,7 +1063,7 @@ def test_compact_tag_map_follows_the_reference_set_order_on_device(dev):
             assert [int(tm[t]) for t in raw] == want
 
 
-def test_full_size_headline_instance_properties(dev):
+def test_full_size_headline_instance_properties(dev, lpg_options):
     """The bench's own instance -- RMAT |V| = 5 M, |E| = 100 M, d = 128 fp32 (BASELINE north-star target) -- through
     size-independent properties: degree() == bincount (int64, bit-exact), CSR row lengths == in-degrees and every
     row's columns == the sources in edge order on a sample, column checksum of Y in fp64, exact scaling by 2,
@@ -1093,6 +1093,33 @@ def test_full_size_headline_instance_properties(dev):
     assert torch.all((y.double().sum(0) - want).abs() <= 1e-6 * mag)
     assert torch.equal(g.spmm(2.0 * x), 2.0 * y)
     assert torch.equal(g.spmm(x), y)
+    # the rows without edges are filled on a second stream beside the main kernel (big graphs only): same bits as the
+    # one-stream order, into a buffer full of NaN, bias + activation on them included, and inside a stream capture
+    # (where the fork is not taken)
+    empty = deg == 0
+    assert g.n_empty == int(empty.sum()) > N // 10
+    bias = torch.randn(d, generator=gen, device=dev)
+    outs = []
+    for overlap in (1, 0):
+        lpg_options(spmm_fill_overlap=overlap)
+        buf = torch.full((N, d), float("nan"), device=dev)
+        outs.append(g.spmm(x, bias=bias, act="relu", out=buf))
+    assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0][empty], bias.clamp(min=0).expand(int(empty.sum()), d))
+    del outs, buf
+    lpg_options(spmm_fill_overlap=1)
+    side, cg, yc = torch.cuda.Stream(), torch.cuda.CUDAGraph(), torch.full((N, d), float("nan"), device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g.spmm(x, out=yc)                                # warm-up on the capture stream (workspace allocation)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(cg, stream=side):
+        g.spmm(x, out=yc)
+    yc.fill_(float("nan"))
+    cg.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yc, y)
+    del cg, yc
     for r in rows.tolist():
         src = ei[0][ei[1] == r]
         ref, mg = x[src].double().sum(0), x[src].double().abs().sum(0)
