@@ -47,7 +47,9 @@ int lpg_abi_version(void);
  * paths read with plain loads -- the library never calls getenv on a launch path, and a release build never reads
  * the environment at all.  Every value a release build accepts selects between variants that all return correct
  * results (the tests pin each to the oracle): "spmm_chunk", "spmm_mode" (0 / 1), "spmm_lds", "spmm_block",
- * "spmm_off32", "spmm_rows_max", "spmm_rows_ecap", "spmm_no_edge", "seal_conv_fp32", "gn_small",
+ * "spmm_off32", "spmm_rows_max", "spmm_rows_ecap", "spmm_no_edge", "spmm_fill_overlap" (1: big graphs fill
+ * their edge-less rows on a library-owned second stream beside the main kernel, joined before the call's work on the
+ * caller's stream ends; never inside a stream capture), "seal_conv_fp32", "gn_small",
  * "seal_conv_variant", "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant),
  * "linear_x3" (-1 automatic, 0 off, 1 force: the fp32 linear as exact three-plane bf16 products, csrc/linear_x3.hip), "seal_pair_small",
  * "spmm_phase_timing" (1: lpg_csr_spmm_* record events around their kernels, see lpg_csr_spmm_phase_ms).
