@@ -37,6 +37,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;
 constexpr int kBlockX3 = 512;
 constexpr int kWavesX3 = kBlockX3 / 64;
 constexpr size_t kLdsBudgetX3 = 148 * 1024;
+constexpr int kMaxDevX3 = 16;
 constexpr int kAheadX3 = 4;            // 32-wide k groups a wave's loads run ahead of its MFMAs (16 KB in flight per wave)
 
 __device__ __forceinline__ void split3u(float v, uint32_t& hi, uint32_t& mid, uint32_t& lo) {   // the three terms as fp32 bit patterns with 16 zero low bits
@@ -286,17 +287,17 @@ __global__ __launch_bounds__(kBlockX3) void linear_x3_kernel(const float* __rest
 
 template <int NT>
 int launch_x3(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, int act, float* y, int64_t ldy,
-              int64_t n, int k, int m, int kpad, int cus, hipStream_t st) {
+              int64_t n, int k, int m, int kpad, int cus, int dev, hipStream_t st) {
   const size_t lds = static_cast<size_t>(3) * NT * 32 * kpad * 2 + NT * 32 * 4;
   auto kern = linear_x3_kernel<NT>;
-  static bool attr_set = false;                           // per instantiation
-  if (!attr_set) {
+  static bool attr_set[kMaxDevX3] = {};                   // per instantiation and device (a code object is loaded per device)
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       set_error("linear (bf16 planes): cannot raise the dynamic LDS limit");
       return LPG_E_LAUNCH;
     }
-    attr_set = true;
+    attr_set[dev] = true;
   }
   const int strips = static_cast<int>(ceil_div(m, NT * 32));
   const int64_t n_tiles = ceil_div(n, 32);
@@ -334,18 +335,18 @@ int linear_x3_f32(const float* x, int64_t ldx, const float* w, int w_is_km, cons
     if ((k * m) / (2 * (k + m)) < 20) return 0;
     if (n < (k * m > 128 * 128 ? 16384 : 57344)) return 0;
   }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevX3) return 0;
+  static int cus_of[kMaxDevX3] = {};
+  if (!cus_of[dev] &&
+      (hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_of[dev] <= 0))
+    cus_of[dev] = 256;
+  const int cus = cus_of[dev];
   const int ki = static_cast<int>(k), mi = static_cast<int>(m);
   int rc;
-  if (nt == 1) rc = launch_x3<1>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, kpad, cus, st);
-  else if (nt == 2) rc = launch_x3<2>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, kpad, cus, st);
-  else rc = launch_x3<4>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, kpad, cus, st);
+  if (nt == 1) rc = launch_x3<1>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, kpad, cus, dev, st);
+  else if (nt == 2) rc = launch_x3<2>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, kpad, cus, dev, st);
+  else rc = launch_x3<4>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, kpad, cus, dev, st);
   if (rc == 1) ++options_mut().stat_linear_x3;
   return rc;
 }
