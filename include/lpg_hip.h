@@ -227,6 +227,11 @@ int lpg_flip_index_i64(const int64_t* ei2, int64_t E2, int64_t* edge, int64_t* e
  * lpg_small_gcn_f32: y[n, ldo] (column c) = dinv * (A (dinv * h[:, c])) + bias[c] and `part`, for one
  *   or two (graph, bias) sets in one launch (conv2s[i] / conv2s_r[i], model.py:77; both graphs packed
  *   with the same e_cap and row_blocks); second set NULL = one side.  Atomic-free, fixed order.
+ * lpg_small_gcn_embed_f32: the same aggregation for conv1 of a model without node features
+ *   [model.py:53-55,71-73: x = GraphNorm(Embedding(deg)); conv1 = GCNConv(x, edge1)]: the feature column
+ *   h[:, c] = GraphNorm(table[idx]) W[c, :] is made inside the launch from the table (n_table, k <= 1024), the
+ *   index histogram and the distinct rows' products -- lpg_embedding_graphnorm_f32 + lpg_small_linear_t_f32 +
+ *   lpg_small_gcn_f32 in one launch; out-of-range idx sets err_flag (row 0 is used).
  * lpg_small_readout_f32: out[b] = sum_c x[idx[2b],c] * x[idx[2b+1],c] * w[c] + b0 with
  *   x = N_a(ya) + N_r(yr)  (yr NULL: x = N_a(ya))  [model.py:77-83]. */
 int64_t lpg_small_max_rows(void);
@@ -253,6 +258,12 @@ int lpg_small_gcn_f32(int64_t n, int64_t c, int64_t ldt, int64_t ldo, int64_t ro
                       const float* hT2, const void* pack2, const int64_t* rowptr2,
                       const float* dinv2, const float* bias2, float* y2, double* part2,
                       void* stream);
+int lpg_small_gcn_embed_f32(int64_t n, int64_t c, int64_t ldo, int64_t row_blocks, int64_t e_cap,
+                            const float* table, int64_t n_table, int64_t k, const int64_t* idx,
+                            const float* gn_weight, const float* gn_bias, const float* gn_mean_scale,
+                            float eps, const float* lin_w, const void* pack, const int64_t* rowptr,
+                            const float* dinv, const float* bias, float* y, double* part,
+                            int32_t* err_flag, void* stream);
 int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C,
                           const double* part_a, const float* gn_weight_a, const float* gn_bias_a,
                           const float* gn_mean_scale_a, int64_t row_blocks_a, int relu_a,
@@ -263,7 +274,7 @@ int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C
 /* The whole small-graph scoring forward of LocalWLNet (TwoWL/model/model.py:68-84; the timed call of
  * TwoWL/model/train.py:54-60) as ONE call: `block` (HOST memory, n_words int64 words) lists the forward's launches in
  * order as { op, a_0 .. a_{k-1} } -- op 1: lpg_embedding_graphnorm_f32 (k = 12), 2: lpg_small_linear_t_f32 (27),
- * 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23); a_i = that entry point's i-th argument (pointers and
+ * 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23), 5: lpg_small_gcn_embed_f32 (21); a_i = that entry point's i-th argument (pointers and
  * integers as they are, `float eps` as the bit pattern of a double; the trailing stream argument is left out).  Every
  * launch goes through the same entry point as the one-by-one path and is enqueued on `stream`: same kernels, same
  * results, one host call per forward instead of six (the forward is launch-bound: 205 -> ~60 us eager).

@@ -278,11 +278,28 @@ struct SgSide {
   double* part;             // [rb][2][c] column sums of y and y^2 per row block
 };
 
+// conv1 of LocalWLNet without node features (TwoWL/model/model.py:71-73): the layer's input is GraphNorm(Embedding(deg)),
+// i.e. a table of n_table rows gathered by idx.  With `table` set, the column workgroup makes its feature column itself
+// -- idx histogram -> GraphNorm statistics (the fp64 one-pass formula of gn_small_kernel, weighted by the histogram) ->
+// one value per DISTINCT index: T'[v] = sum_k GN(table[v][k]) W[c][k] -> hs[r] = T'[idx[r]] -- instead of reading it from
+// sg_linear_t_kernel's output: lpg_embedding_graphnorm_f32 + lpg_small_linear_t_f32 + lpg_small_gcn_f32 in one launch.
+struct SgEmbed {
+  const float* table;       // [n_table, k] (null: not used)
+  const int64_t* idx;       // [n]
+  int n_table, k;
+  const float* gn_w;        // GraphNorm weight / bias / mean_scale [k] (null: 1 / 0 / 1)
+  const float* gn_b;
+  const float* gn_ms;
+  float eps;
+  const float* lin_w;       // [c, k] GCNConv.lin.weight
+  int32_t* err_flag;
+};
+
 // RT = rows per thread of the LONGER of (all rows: the column fill) and nothing else -- ceil(n / 1024); absent rows are
 // clamped duplicate loads, and at 620 rows seven of eight were
-template <int RT>
+template <int RT, bool EMB>
 __global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const SgSide s1, int n, int rb, int64_t ldt,
-                                                          int64_t ldo, int64_t cap_words) {
+                                                          int64_t ldo, int64_t cap_words, const SgEmbed em) {
   __shared__ float hs[kSgMaxRows];
   __shared__ float acc[kSgMaxRows];
   __shared__ int first_row[kSgBlock], last_row[kSgBlock];
@@ -305,13 +322,125 @@ __global__ __launch_bounds__(kSgBlock) void sg_gcn_kernel(const SgSide s0, const
 #pragma unroll
   for (int b = 0; b < kBatch; ++b) u[b] = pk[static_cast<int64_t>(b < q_cap ? b : q_cap - 1) * kSgBlock + t];
   float dv[RT];
+  int iv[RT];                                            // EMB: the rows' table indices
+  if constexpr (EMB) {
+    // LDS that the aggregation uses later serves the prologue: hist / the list of present indices / T' / the column's
+    // GraphNorm shift, scale, bias and weight row
+    int* const hist = first_row;
+    int* const plist = last_row;
+    float* const tcol = l_sum;
+    float* const sh = acc;
+    float* const sc = acc + kSgBlock;
+    float* const bi = acc + 2 * kSgBlock;
+    float* const wr = acc + 3 * kSgBlock;
+    double* const psum = reinterpret_cast<double*>(hs);  // [2][kSgBlock] partial column sums (16 KB of the 32)
+    __shared__ int wcnt[kSgBlock / 64];
+    const int k = em.k;
+    hist[t] = 0;
+    // parameter loads up front
+    float p_w = 1.f, p_b = 0.f, p_ms = 1.f, wv = 0.f;
+    if (t < k) {
+      if (em.gn_w) p_w = em.gn_w[t];
+      if (em.gn_b) p_b = em.gn_b[t];
+      if (em.gn_ms) p_ms = em.gn_ms[t];
+      wv = em.lin_w[static_cast<int64_t>(c) * k + t];
+    }
+    int64_t v64[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int r = t + i * kSgBlock;
+      v64[i] = em.idx[r < n ? r : n - 1];
+    }
+    __syncthreads();
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const bool b = v64[i] < 0 || v64[i] >= em.n_table;
+      bad |= b;
+      iv[i] = b ? 0 : static_cast<int>(v64[i]);
+      if (t + i * kSgBlock < n) atomicAdd(&hist[iv[i]], 1);
+    }
+    if (bad) flag_error(em.err_flag, LPG_F_INDEX_RANGE);
+    __syncthreads();
+    // the distinct indices in ascending order (the summation order below must not depend on the run)
+    const bool pres = t < em.n_table && hist[t] > 0;
+    const uint64_t bal = __ballot(pres);
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0, npres = 0;
+    for (int w2 = 0; w2 < kSgBlock / 64; ++w2) {
+      if (w2 < wave) base += wcnt[w2];
+      npres += wcnt[w2];
+    }
+    if (pres) plist[base + __popcll(bal & ((uint64_t(1) << lane) - 1))] = t;
+    __syncthreads();
+    // column sums over the n gathered rows = histogram-weighted sums over the distinct table rows; the threads beyond
+    // k take every G-th present row of column t mod kp so that the loads of a column are spread over G threads
+    int kp = 64;
+    while (kp < k) kp <<= 1;
+    const int G = kSgBlock / kp, col = t & (kp - 1), grp = t / kp;
+    {
+      double ps = 0.0, ps2 = 0.0;
+      if (col < k) {
+        constexpr int U = 8;
+        for (int j0 = grp; j0 < npres; j0 += G * U) {
+          float xq[U];
+          int hq[U];
+#pragma unroll
+          for (int q = 0; q < U; ++q) {
+            const int j = j0 + q * G;
+            const int vv = plist[j < npres ? j : npres - 1];
+            hq[q] = j < npres ? hist[vv] : 0;
+            xq[q] = em.table[static_cast<int64_t>(vv) * k + col];
+          }
+#pragma unroll
+          for (int q = 0; q < U; ++q) {
+            const double xd = static_cast<double>(xq[q]), hd = static_cast<double>(hq[q]);
+            ps += hd * xd;
+            ps2 += hd * xd * xd;
+          }
+        }
+      }
+      psum[t] = ps;
+      psum[kSgBlock + t] = ps2;
+    }
+    __syncthreads();
+    if (t < k) {
+      double ts = 0.0, ts2 = 0.0;
+      for (int gq = 0; gq < G; ++gq) { ts += psum[gq * kp + t]; ts2 += psum[kSgBlock + gq * kp + t]; }   // fixed order
+      const double mean = ts / static_cast<double>(n), ex2 = ts2 / static_cast<double>(n);
+      const double ms = static_cast<double>(p_ms);
+      double var = ex2 - mean * mean * ms * (2.0 - ms);
+      if (var < 0.0) var = 0.0;
+      const double inv = 1.0 / sqrt(var + static_cast<double>(em.eps));
+      sh[t] = static_cast<float>(mean * ms);
+      sc[t] = static_cast<float>(static_cast<double>(p_w) * inv);
+      bi[t] = p_b;
+      wr[t] = wv;
+    }
+    __syncthreads();
+    // T'[v] = sum_k ((table[v][k] - shift_k) * scale_k + bias_k) * W[c][k] for the distinct v: a wave per v
+    for (int j = wave; j < npres; j += kSgBlock / 64) {
+      const int vv = plist[j];
+      float pacc = 0.f;
+      for (int cc = lane; cc < k; cc += 64) {
+        const float xg = (em.table[static_cast<int64_t>(vv) * k + cc] - sh[cc]) * sc[cc] + bi[cc];
+        pacc = fmaf(xg, wr[cc], pacc);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) pacc += __shfl_xor(pacc, o);
+      if (lane == 0) tcol[vv] = pacc;
+    }
+    __syncthreads();
+  }
   {
     float hv[RT], dd[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int r = t + i * kSgBlock;
       const int rc = r < n ? r : n - 1;
-      hv[i] = s.hT[static_cast<int64_t>(c) * ldt + rc];
+      if constexpr (EMB) hv[i] = l_sum[iv[i]];
+      else hv[i] = s.hT[static_cast<int64_t>(c) * ldt + rc];
       dd[i] = s.dinv[rc];
       const int rl = r0 + r;
       dv[i] = s.dinv[rl < n ? rl : n - 1];
@@ -558,15 +687,43 @@ LPG_EXPORT int lpg_small_gcn_f32(int64_t n, int64_t c, int64_t ldt, int64_t ldo,
   if (two) s1 = SgSide{hT2, static_cast<const uint32_t*>(pack2), rowptr2, dinv2, bias2, y2, part2};
   const dim3 grid(static_cast<unsigned>(c), static_cast<unsigned>(row_blocks), two ? 2 : 1);
   const int rows = static_cast<int>((n + kSgBlock - 1) / kSgBlock);
+  const SgEmbed em{};
 #define LPG_SG_GCN(RTV)                                                                                               \
-  hipLaunchKernelGGL(sg_gcn_kernel<RTV>, grid, dim3(kSgBlock), 0, as_stream(stream), s0, s1, static_cast<int>(n),     \
-                     static_cast<int>(row_blocks), ldt, ldo, sg_strip(e_cap) * kSgBlock)
+  hipLaunchKernelGGL((sg_gcn_kernel<RTV, false>), grid, dim3(kSgBlock), 0, as_stream(stream), s0, s1, static_cast<int>(n), \
+                     static_cast<int>(row_blocks), ldt, ldo, sg_strip(e_cap) * kSgBlock, em)
   if (rows <= 1) LPG_SG_GCN(1);
   else if (rows <= 2) LPG_SG_GCN(2);
   else if (rows <= 4) LPG_SG_GCN(4);
   else LPG_SG_GCN(8);
 #undef LPG_SG_GCN
   return check_launch("small_gcn");
+}
+
+LPG_EXPORT int lpg_small_gcn_embed_f32(int64_t n, int64_t c, int64_t ldo, int64_t row_blocks, int64_t e_cap,
+                                       const float* table, int64_t n_table, int64_t k, const int64_t* idx,
+                                       const float* gn_weight, const float* gn_bias, const float* gn_mean_scale, float eps,
+                                       const float* lin_w, const void* pack, const int64_t* rowptr, const float* dinv,
+                                       const float* bias, float* y, double* part, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(n >= 1 && n <= kSgMaxRows && c >= 1 && c < 65536 && rb_ok(row_blocks) && e_cap >= 0,
+              "small_gcn_embed: needs 1 <= n <= %d, 1 <= row_blocks <= %d", kSgMaxRows, kSgMaxRowBlocks);
+  LPG_REQUIRE(n_table >= 1 && n_table <= kSgBlock && k >= 1 && k <= kSgBlock,
+              "small_gcn_embed: needs a table of at most %d rows and %d columns", kSgBlock, kSgBlock);
+  LPG_REQUIRE(table && idx && lin_w && pack && rowptr && dinv && y && part && ldo >= c, "small_gcn_embed: bad argument");
+  LPG_REQUIRE(al16(pack), "small_gcn_embed: pack must be 16-byte aligned");
+  const SgSide s0{nullptr, static_cast<const uint32_t*>(pack), rowptr, dinv, bias, y, part};
+  const SgEmbed em{table, idx, static_cast<int>(n_table), static_cast<int>(k), gn_weight, gn_bias, gn_mean_scale, eps, lin_w,
+                   err_flag};
+  const dim3 grid(static_cast<unsigned>(c), static_cast<unsigned>(row_blocks), 1);
+  const int rows = static_cast<int>((n + kSgBlock - 1) / kSgBlock);
+#define LPG_SG_GCN_E(RTV)                                                                                             \
+  hipLaunchKernelGGL((sg_gcn_kernel<RTV, true>), grid, dim3(kSgBlock), 0, as_stream(stream), s0, s0, static_cast<int>(n), \
+                     static_cast<int>(row_blocks), n, ldo, sg_strip(e_cap) * kSgBlock, em)
+  if (rows <= 1) LPG_SG_GCN_E(1);
+  else if (rows <= 2) LPG_SG_GCN_E(2);
+  else if (rows <= 4) LPG_SG_GCN_E(4);
+  else LPG_SG_GCN_E(8);
+#undef LPG_SG_GCN_E
+  return check_launch("small_gcn_embed");
 }
 
 LPG_EXPORT int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C, const double* part_a,
@@ -592,7 +749,8 @@ LPG_EXPORT int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P
 // on them (argument marshalling, tensor bookkeeping, one call per kernel).  The host mirror therefore prepares an
 // ARGUMENT BLOCK once per (model, graph, candidate set): the launches of the forward, in order, as int64 words
 //     { op, a_0, ..., a_{k-1} }  per launch,  op in {1: lpg_embedding_graphnorm_f32 (12 words),
-//     2: lpg_small_linear_t_f32 (27), 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23)},
+//     2: lpg_small_linear_t_f32 (27), 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23),
+//     5: lpg_small_gcn_embed_f32 (21)},
 // a_i = the entry point's i-th argument (pointers and integers as they are, `float eps` as the bit pattern of a
 // double), the trailing `stream` argument left out.  lpg_twowl_forward_small walks the block and enqueues every
 // launch on `stream` through the very same entry points (same checks, same kernels, same results as calling them
@@ -612,7 +770,7 @@ LPG_EXPORT int lpg_twowl_forward_small(const int64_t* block, int64_t n_words, vo
   while (i < n_words) {
     const int64_t op = block[i];
     const int64_t* a = block + i + 1;
-    const int64_t need = op == 1 ? 12 : op == 2 ? 27 : op == 3 ? 20 : op == 4 ? 23 : -1;
+    const int64_t need = op == 1 ? 12 : op == 2 ? 27 : op == 3 ? 20 : op == 4 ? 23 : op == 5 ? 21 : -1;
     LPG_REQUIRE(need > 0 && i + 1 + need <= n_words, "twowl_forward_small: malformed block at word %lld (op %lld)",
                 (long long)i, (long long)op);
     int rc = LPG_OK;
@@ -632,6 +790,12 @@ LPG_EXPORT int lpg_twowl_forward_small(const int64_t* block, int64_t n_words, vo
                              wp<const int64_t>(a[8]), wp<const float>(a[9]), wp<const float>(a[10]), wp<float>(a[11]),
                              wp<double>(a[12]), wp<const float>(a[13]), wp<const void>(a[14]), wp<const int64_t>(a[15]),
                              wp<const float>(a[16]), wp<const float>(a[17]), wp<float>(a[18]), wp<double>(a[19]), stream);
+    } else if (op == 5) {
+      rc = lpg_small_gcn_embed_f32(a[0], a[1], a[2], a[3], a[4], wp<const float>(a[5]), a[6], a[7], wp<const int64_t>(a[8]),
+                                   wp<const float>(a[9]), wp<const float>(a[10]), wp<const float>(a[11]), wf(a[12]),
+                                   wp<const float>(a[13]), wp<const void>(a[14]), wp<const int64_t>(a[15]),
+                                   wp<const float>(a[16]), wp<const float>(a[17]), wp<float>(a[18]), wp<double>(a[19]),
+                                   wp<int32_t>(a[20]), stream);
     } else {
       rc = lpg_small_readout_f32(wp<const float>(a[0]), wp<const float>(a[1]), a[2], a[3], wp<const double>(a[4]),
                                  wp<const float>(a[5]), wp<const float>(a[6]), wp<const float>(a[7]), a[8],

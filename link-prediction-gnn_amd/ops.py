@@ -577,6 +577,31 @@ def small_gcn(n, sides):
     return outs
 
 
+SMALL_EMBED_MAX = 1024      # table rows / columns lpg_small_gcn_embed_f32 takes (a 1024-thread workgroup: one thread each)
+
+
+def small_gcn_embed(n, table, idx, gn_weight, gn_bias, gn_mean_scale, eps, lin_weight, g, bias, norm, relu):
+    """conv1 of a model without node features in ONE launch: A_hat (GraphNorm(table[idx]) W^T) + bias, un-normalised,
+    as a `Deferred` (lpg_small_gcn_embed_f32).  table [n_table, k] (both <= 1024), idx int64 [n], lin_weight [c, k],
+    g: gcn-normalised unit-weight CSRGraph of n rows."""
+    table, lin_weight = _c(table, torch.float32), _c(lin_weight, torch.float32)
+    idx = _c(idx.reshape(-1), torch.int64)
+    gw, gb, gms, b = (_c(v, torch.float32) for v in (gn_weight, gn_bias, gn_mean_scale, bias))
+    _need_gpu(table, idx, lin_weight, gw, gb, gms, b)
+    c, k = lin_weight.shape
+    if table.shape[1] != k or idx.numel() != n or g.n_rows != n or g.n_cols != n or not g.unit_gcn:
+        raise ValueError("small_gcn_embed: shapes do not match (table [*, k], idx [n], W [c, k], square gcn graph of n rows)")
+    rb = small_row_blocks(g.e_cap)
+    y = torch.empty((n, c), dtype=torch.float32, device=table.device)
+    part = torch.empty((rb, 2, c), dtype=torch.float64, device=table.device)
+    pack = g.small_pack(rb)
+    _lib.keepalive(table, idx, lin_weight, gw, gb, gms, b, pack, g.rowptr, g.dinv, y, part)
+    _lib.call("lpg_small_gcn_embed_f32", n, c, c, rb, g.e_cap, _ptr(table), table.shape[0], k, _ptr(idx), _ptr(gw), _ptr(gb),
+              _ptr(gms), float(eps), _ptr(lin_weight), _ptr(pack), _ptr(g.rowptr), _ptr(g.dinv), _ptr(b), _ptr(y), _ptr(part),
+              _ptr(err_flag(table.device)), _stream())
+    return Deferred(y, part, norm, relu)
+
+
 def small_readout(a, r, idx, w, b):
     """pair readout over N(a) + N(r) (r may be None); a, r: `Deferred` [P, C]."""
     lib = _lib.load()

@@ -51,6 +51,7 @@ def double(x, for_index=False):
 _side_streams = {}
 _PARALLEL_BRANCHES = os.environ.get("LPG_TWOWL_PARALLEL", "1") != "0"
 _SMALL_PATH = os.environ.get("LPG_TWOWL_SMALL", "1") != "0"      # A/B hook: 0 keeps the kernel-per-op path
+_FUSE_EMBED = True          # small path: Embedding + GraphNorm + conv1 in one launch (False: three, for A/B and tests)
 
 
 def _is_relu_conv(seq):
@@ -204,15 +205,25 @@ class LocalWLNet(nn.Module):
         + bias per (feature column, row block) out of LDS), GraphNorm + ReLU deferred into whichever kernel reads
         the result next, embedding + GraphNorm in one launch, the pair product folded into the first 2-WL linear,
         both orientations of a 2-WL layer in the same two launches, their sum folded into the next linear / the
-        readout.  21 launches -> 6 at depth 1/1."""
+        readout.  21 launches -> 4 at depth 1/1 (conv1 of a model without node features makes its own input from the
+        embedding table: one launch for Embedding, GraphNorm, the linear and the aggregation)."""
         N, P = (self.node_feat.shape[0] if self.use_node_feat else x.shape[0]), pos.shape[0]
         g1 = graph_cache.get(edge1, None, N, True)
+        convs = list(self.conv1s)
         if self.use_node_feat:
             h = self._input_features(x)
+        elif (_FUSE_EMBED and convs and self.emb[0].weight.shape[0] <= _ops.SMALL_EMBED_MAX
+              and self.emb[0].weight.shape[1] <= _ops.SMALL_EMBED_MAX):
+            # Embedding -> GraphNorm -> conv1's linear -> conv1's aggregation in ONE launch (the degrees take a few
+            # dozen distinct values: the layer's input has that many distinct rows)
+            norm0, seq = self.emb[1], convs.pop(0)
+            h = _ops.small_gcn_embed(N, self.emb[0].weight, x, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps,
+                                     seq.modlist[0].lin.weight, g1, seq.modlist[0].bias, seq.modlist[1],
+                                     isinstance(seq.modlist[3], nn.ReLU))
         else:
             norm0 = self.emb[1]
             h = _ops.embedding_graph_norm(self.emb[0].weight, x, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps)
-        for seq in self.conv1s:
+        for seq in convs:
             hT = _ops.small_linear_t(h, seq.modlist[0].lin.weight)
             h, = _ops.small_gcn(N, [_side(hT, g1, seq)])
         a = r = None

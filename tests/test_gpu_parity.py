@@ -662,10 +662,64 @@ def test_localwl_small_path_matches_generic_path(dev, tw, monkeypatch):
         assert not mod._small_graph_ok(t(x_deg), t(ei), pos1.shape[0])
         generic = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), pred.shape[1], t(ei2))
         monkeypatch.setattr(twowl, "_SMALL_PATH", True)
+        monkeypatch.setattr(twowl, "_FUSE_EMBED", False)          # conv1 as embedding + linear + aggregation launches
+        mod.invalidate_plans()
+        unfused = twowl.test_forward(mod, t(x_deg), t(ei), t(pos1), pred.shape[1], t(ei2))
+        monkeypatch.setattr(twowl, "_FUSE_EMBED", True)
+        mod.invalidate_plans()
         scale = np.abs(last["out"]).max()
-        for got in (small, generic):
+        for got in (small, generic, unfused):
             assert np.abs(_np(got).astype(np.float64) - last["out"]).max() <= TOL * scale
         assert np.abs(_np(small).astype(np.float64) - _np(generic)).max() <= 2 * TOL * scale
+
+
+@pytest.mark.parametrize("n,E,n_table,k,c", [(620, 3480, 111, 256, 32), (4252, 40000, 1024, 24, 16), (1, 0, 3, 8, 4),
+                                            (3000, 9000, 40, 100, 40), (8192, 30000, 700, 1024, 8)])
+def test_small_gcn_embed(dev, n, E, n_table, k, c):
+    """lpg_small_gcn_embed_f32 -- Embedding -> GraphNorm -> GCNConv.lin -> A_hat-aggregation + bias of conv1 in ONE
+    launch (TwoWL/model/model.py:53-55,71-73) -- against fp64 of the same chain (1e-5 of the magnitude summed at every
+    stage: the per-op bound), against the three launches it replaces, bit-reproducible, out-of-range indices flagged."""
+    import lpgnn_amd
+    from lpgnn_amd import ops, nn as lnn
+    rng = np.random.default_rng(n + k)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32)).to(dev)
+    table = f(n_table, k) * 0.5 + f(1, k)                  # columns with different means and scales
+    idx = torch.from_numpy(np.minimum(rng.zipf(1.6, size=n) - 1, n_table - 1).astype(np.int64)).to(dev)   # few distinct, skewed
+    idx[0] = n_table - 1
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, E))).to(dev)
+    g = lpgnn_amd.CSRGraph.from_edge_index(ei, n, n, gcn_self_loops=True)
+    g.gcn_normalize_()
+    norm0, norm1 = lnn.GraphNorm(k).to(dev), lnn.GraphNorm(c).to(dev)
+    with torch.no_grad():
+        for p_ in (norm0.weight, norm0.bias, norm0.mean_scale):
+            p_.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, size=k).astype(np.float32)))
+    W, bias = f(c, k) * 0.2, f(c)
+    got = ops.small_gcn_embed(n, table, idx, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps, W, g, bias, norm1, True)
+    again = ops.small_gcn_embed(n, table, idx, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps, W, g, bias, norm1, True)
+    assert torch.equal(got.y, again.y) and torch.equal(got.part, again.part)
+    # fp64 chain
+    x = table.double()[idx]
+    mean, ms = x.mean(0), norm0.mean_scale.double()
+    out = x - mean * ms
+    xg = norm0.weight.double() * out / torch.sqrt((out * out).mean(0) + norm0.eps) + norm0.bias.double()
+    from oracle import aggregation as agg
+    ei_np, W_np, b_np = _np(ei), _np(W).astype(np.float64), _np(bias).astype(np.float64)
+    want = torch.from_numpy(agg.gcn_conv(_np(xg), ei_np, W_np, b_np)).to(dev)
+    mag = torch.from_numpy(agg.gcn_conv(np.abs(_np(xg)), ei_np, np.abs(W_np), np.abs(b_np))).to(dev)
+    assert torch.all((got.y.double() - want).abs() <= TOL * (mag + 1.0))
+    assert torch.all((got.part[:, 0].sum(0) - want.sum(0)).abs() <= TOL * (mag.sum(0) + 1.0))
+    # the three launches it replaces
+    if k <= 256:                                           # (lpg_small_linear_t_f32 takes k <= 256)
+        hx = ops.embedding_graph_norm(table, idx, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps)
+        ref, = ops.small_gcn(n, [(ops.small_linear_t(hx, W), g, bias, norm1, True)])
+        assert torch.all((got.y.double() - ref.y.double()).abs() <= 2 * TOL * (mag + 1.0))
+        assert torch.allclose(got.materialize(), ref.materialize(), rtol=0, atol=float(2e-4))
+    # an index outside the table: flagged, never dereferenced
+    bad = idx.clone()
+    bad[n // 2] = n_table + 5
+    ops.small_gcn_embed(n, table, bad, norm0.weight, norm0.bias, norm0.mean_scale, norm0.eps, W, g, bias, norm1, True)
+    with pytest.raises(IndexError):
+        ops.raise_if_flagged(dev)
 
 
 @pytest.mark.parametrize("n,k,m", [(620, 256, 32), (4252, 32, 32), (1, 24, 16), (7, 64, 24), (1030, 100, 40),
@@ -1146,7 +1200,8 @@ def test_small_forward_plan_replay(dev, tw):
     y_len = pred.shape[1]
     first = twowl.test_forward(mod, xd, eit, p1, y_len, e2)              # records
     plan = mod._plan
-    assert plan is not None and plan.n_words == (1 + 12) + 2 * (1 + 27) + 2 * (1 + 20) + (1 + 23)
+    # four launches: conv1 with its input made in the kernel (op 5), the 2-WL linear, the 2-WL aggregation, the readout
+    assert plan is not None and plan.n_words == (1 + 21) + (1 + 27) + (1 + 20) + (1 + 23)
     second = twowl.test_forward(mod, xd, eit, p1, y_len, e2)             # replays the block
     third = twowl.test_forward(mod, xd, eit, p1, y_len, e2)
     assert mod._plan is plan and torch.equal(first, second) and torch.equal(second, third)
