@@ -343,7 +343,10 @@ int lpg_seal_train_csr_small(const int64_t* pairs, int64_t n_pairs, int64_t n_no
  * batch uses -- the presence table of the global tag compaction [SEAL/config/subgraph.py:84-101].
  * hub_index / hub_bits (optional, both or neither): hub_index[node] (int32, n_graph_nodes entries) = the node's row in
  * the hub bit matrix or -1; hub_bits[row * hub_words + (c >> 5)] bit (c & 31) = hubs row and c are adjacent.  Nodes
- * with more than 256 neighbours should be hubs: their mutual adjacency is then one load instead of a binary search.
+ * with more than hub_degree neighbours should be hubs: their mutual adjacency is then one load instead of a binary search.
+ * hub_degree (>= 1): neighbour lists longer than this are not streamed when the induced adjacency is built -- symmetry
+ * fills those rows from the short lists' side, and the entries between two long rows come from the hub matrix (or a
+ * binary search).  128 on a collab-shaped graph: 0.47 -> 0.34 ms per 100 K pairs against 256; 64 and 192 are slower.
  * One launch, two kinds of workgroup: a pair whose two neighbour lists hold <= 62 entries together (n <= 64, the
  * cap cannot fire: most of a batch) is handled by ONE 64-lane wave (two pairs per workgroup, no workgroup barrier); every
  * other pair by the 128 threads of a workgroup that owns 8 consecutive pairs.  Same outputs bit for bit either way;
@@ -358,7 +361,7 @@ int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_
                        int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes,
                        int32_t* tags, uint32_t* adj_bits, uint8_t* capped, uint8_t* tag_present,
                        const int32_t* hub_index, const uint32_t* hub_bits, int64_t hub_words,
-                       int directed, int32_t* err_flag, void* stream);
+                       int64_t hub_degree, int directed, int32_t* err_flag, void* stream);
 /* Block-diagonal CSR of A~ = A + I over a batch, D^-1 = 1/rowsum(A~), and
  * X = [onehot(tag_map[tag], T) || emb[node]]  [SEAL/config/data.py:94-140].
  * node_off[B+1] = exclusive scan of n_nodes (host-computed or torch.cumsum);

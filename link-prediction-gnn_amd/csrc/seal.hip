@@ -157,7 +157,7 @@ __device__ __forceinline__ void wave_pair(
     const int64_t* __restrict__ pairs, int hop, int max_nb, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
     int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag,
     uint8_t* __restrict__ tag_present, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
-    int hub_words) {
+    int hub_words, int big_deg) {
   const int lane = threadIdx.x & 63;
   const int64_t u64 = pairs[2 * b], v64 = pairs[2 * b + 1];
   if (u64 < 0 || u64 >= n_graph || v64 < 0 || v64 >= n_graph) {
@@ -201,7 +201,7 @@ __device__ __forceinline__ void wave_pair(
     const int da = static_cast<int>(rowptr[a + 1] - ba);
     L.rbase[lane] = ba;
     L.rdeg[lane] = da;
-    isbig = da > 256;
+    isbig = da > big_deg;
     mylen = isbig ? 0 : da;
   }
   const uint64_t bigmask = __ballot(isbig);
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     int64_t B, int hop, int max_nb, int replay, int cap_policy, uint64_t seed, int32_t* __restrict__ nodes_out, int32_t* __restrict__ n_out,
     int32_t* __restrict__ tags_out, uint32_t* __restrict__ adj_out, uint8_t* __restrict__ capped_out, int32_t* err_flag,
     uint8_t* __restrict__ tag_present, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
-    int hub_words, int fused, int directed) {
+    int hub_words, int fused, int directed, int big_deg) {
   const int group = fused > 0 ? fused : 1;           // fused = consecutive pairs per team workgroup (0: not fused)
   // directed != 0 (SEAL/config/subgraph.py:30-31,69 with network_type = 1): the CSR lists SUCCESSORS only and the induced
   // adjacency is not symmetric -- no entry is mirrored, and rows that are not streamed are searched against every column.
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     const int64_t bw = (static_cast<int64_t>(blockIdx.x) - n_groups) * (kSealBlock / 64) + (threadIdx.x >> 6);
     if (bw < B)                                          // wave-uniform; wave_pair has no workgroup barrier
       wave_pair(wp[threadIdx.x >> 6], bw, rowptr, col, n_graph, pairs, hop, max_nb, nodes_out, n_out, tags_out, adj_out,
-                capped_out, err_flag, tag_present, hub_index, hub_bits, hub_words);
+                capped_out, err_flag, tag_present, hub_index, hub_bits, hub_words, big_deg);
     return;
   }
   int32_t (&cand)[2 * MAXN] = lds.team.cand;
@@ -555,14 +555,14 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
       const int da = static_cast<int>(rowptr[a + 1] - ba);
       rbase[t] = ba;
       rdeg[t] = da;
-      if (replay || da > 256) big[atomicAdd(&s_nbig, 1)] = t;     // replayed node lists need not be sorted
+      if (replay || da > big_deg) big[atomicAdd(&s_nbig, 1)] = t;     // replayed node lists need not be sorted
     }
     __syncthreads();
     if (!replay) {
       // exclusive prefix of the streamed rows' list lengths (wave scan + the first wave's total), then the
       // (row, k) items are dealt round-robin to the threads: no thread walks a row alone, and the 4 loads of a
       // round are independent (per-row loops paid one global round trip per row: 20 us for a 100-vertex subgraph)
-      const int mylen = (t < n && rdeg[t] <= 256) ? rdeg[t] : 0;
+      const int mylen = (t < n && rdeg[t] <= big_deg) ? rdeg[t] : 0;
       int inc = mylen;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -1263,10 +1263,11 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
                                   const int64_t* pairs, int64_t B, int hop, int max_neighbors, int replay,
                                   int cap_policy, uint64_t seed, int32_t* nodes, int32_t* n_nodes, int32_t* tags, uint32_t* adj_bits, uint8_t* capped,
                                   uint8_t* tag_present, const int32_t* hub_index, const uint32_t* hub_bits,
-                                  int64_t hub_words, int directed, int32_t* err_flag, void* stream) {
+                                  int64_t hub_words, int64_t hub_degree, int directed, int32_t* err_flag, void* stream) {
   LPG_REQUIRE(B >= 0 && n_graph_nodes >= 0, "seal_subgraphs: bad sizes");
   LPG_REQUIRE(hop == 0 || hop == 1, "seal_subgraphs: hop must be 0 or 1 (the reference itself fails for hop >= 2)");
   LPG_REQUIRE(max_neighbors >= 2 && max_neighbors <= MAXN, "seal_subgraphs: max_neighbors must be in [2, %d]", MAXN);
+  LPG_REQUIRE(hub_degree >= 1 && hub_degree < (int64_t(1) << 30), "seal_subgraphs: hub_degree must be >= 1");
   if (B == 0) return LPG_OK;
   LPG_REQUIRE(adj_rowptr && pairs && nodes && n_nodes && tags && adj_bits && capped, "seal_subgraphs: null pointer");
   hipStream_t st = as_stream(stream);
@@ -1282,7 +1283,7 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
   const int64_t grid = fused ? ceil_div(B, group) + ceil_div(B, kSealBlock / 64) : (B < (int64_t(1) << 24) ? B : (int64_t(1) << 24));
   hipLaunchKernelGGL(seal_subgraph_kernel, dim3(static_cast<unsigned>(grid)), dim3(kSealBlock), 0, st, adj_rowptr, adj_col,
                      n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag,
-                     tag_present, directed ? nullptr : hidx, hub_bits, static_cast<int>(hub_words), fused ? group : 0, directed);
+                     tag_present, directed ? nullptr : hidx, hub_bits, static_cast<int>(hub_words), fused ? group : 0, directed, static_cast<int>(hub_degree));
   return check_launch("seal_subgraphs");
 }
 

@@ -30,18 +30,21 @@ class TrainGraph:
         self.directed = bool(directed)               # network_type = 1: rows list successors only (nx.DiGraph)
         self.hub_index = self.hub_bits = None        # hub bit matrix (build_hub_matrix): hub x hub adjacency in one load
 
-    HUB_DEGREE = 256                                 # the extraction kernel streams shorter neighbour lists
-    MAX_HUBS = 4096                                  # 2 MB of bits
+    HUB_DEGREES = (128, 256)                         # neighbour lists longer than hub_degree are not streamed by the extraction:
+    MAX_HUBS = 4096                                  # the smallest of these that leaves at most MAX_HUBS hubs (2 MB of bits)
+    hub_degree = 256                                 # (until build_hub_matrix chose; 128: 0.47 -> 0.34 ms per 100 K collab-shaped pairs)
 
     def build_hub_matrix(self):
         """hub_index[node] = row in the bit matrix (-1: not a hub), hub_bits[row, c >> 5] bit (c & 31) = hubs row and c
-        are adjacent; hubs = nodes with more than HUB_DEGREE neighbours.  Skipped for graphs with more than
+        are adjacent; hubs = nodes with more than hub_degree neighbours.  Skipped for graphs with more than
         MAX_HUBS of them or fewer than 128 K stored edges (the kernel then binary-searches hub x hub entries as before)."""
         dev = self.rowptr.device
         if self.directed or self.col.numel() < (1 << 17):   # directed: no symmetry for the kernel to lean on; small graphs
             return self                                     # (fb-pages-food): no host sync, the few searches are cheap
         deg = self.rowptr[1:] - self.rowptr[:-1]
-        hubs = torch.nonzero(deg > self.HUB_DEGREE).flatten()
+        counts = [int(v) for v in torch.stack([(deg > d).sum() for d in self.HUB_DEGREES]).tolist()]   # one host read
+        self.hub_degree = next((d for d, cnt in zip(self.HUB_DEGREES, counts) if cnt <= self.MAX_HUBS), self.HUB_DEGREES[-1])
+        hubs = torch.nonzero(deg > self.hub_degree).flatten()
         H = int(hubs.numel())
         if H == 0 or H > self.MAX_HUBS:
             return self
@@ -215,6 +218,7 @@ def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, r
                                       _ops._ptr(tags), _ops._ptr(adj_bits), _ops._ptr(capped), _ops._ptr(present),
                                       _ops._ptr(graph.hub_index), _ops._ptr(graph.hub_bits),
                                       getattr(graph, "hub_words", 0) if graph.hub_bits is not None else 0,
+                                      int(getattr(graph, "hub_degree", 256)),
                                       int(getattr(graph, "directed", False)), _ops._ptr(_ops.err_flag(dev)), _ops._stream()),
                "seal_subgraphs")
     # no sync of its own: the flag is read together with the batch's vertex total (SubgraphBatch.total(), which every

@@ -33,7 +33,7 @@ def test_workspace_queries_and_errors():
         assert q > 0
     rc = lib.lpg_csr_spmm_f32(0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 10, 0, 0, 0, 0, -1, -1, 0, 0, 0)
     assert rc == -1 and b"bad sizes" in lib.lpg_last_error()
-    rc = lib.lpg_seal_subgraphs(0, 0, 10, 0, 4, 2, 100, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    rc = lib.lpg_seal_subgraphs(0, 0, 10, 0, 4, 2, 100, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 256, 0, 0, 0)
     assert rc == -1 and b"hop" in lib.lpg_last_error()
     rc = lib.lpg_linear_f32(0, 4, 0, 0, 0, 0, 0, 4, 8, 0, 4, 0)
     assert rc == -1

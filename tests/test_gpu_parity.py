@@ -1358,7 +1358,7 @@ def test_seal_hub_bit_matrix_matches_searches(dev):
     assert graph.hub_bits is not None and graph.hub_index is not None
     H = graph.hub_bits.shape[0]
     deg = graph.rowptr[1:] - graph.rowptr[:-1]
-    assert H == int((deg > seal.TrainGraph.HUB_DEGREE).sum()) and H > 10
+    assert H == int((deg > graph.hub_degree).sum()) and H > 10
     hubs = torch.nonzero(graph.hub_index >= 0).flatten()
     rng = np.random.default_rng(0)
     bits = _np(graph.hub_bits).view(np.uint32)

@@ -44,7 +44,7 @@ def test_hub_bit_matrix_on_cpu():
     g = seal.build_train_csr(pos, n, test_ratio=0.0, device="cpu")
     assert g.hub_bits is not None and g.col.numel() >= (1 << 17)
     deg = (g.rowptr[1:] - g.rowptr[:-1]).numpy()
-    hub_nodes = np.nonzero(deg > seal.TrainGraph.HUB_DEGREE)[0]
+    hub_nodes = np.nonzero(deg > g.hub_degree)[0]
     assert set(hubs.tolist()) <= set(hub_nodes.tolist()) and g.hub_bits.shape[0] == len(hub_nodes)
     idx = g.hub_index.numpy()
     assert np.array_equal(np.nonzero(idx >= 0)[0], hub_nodes) and np.array_equal(idx[hub_nodes], np.arange(len(hub_nodes)))
