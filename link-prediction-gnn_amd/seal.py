@@ -30,9 +30,13 @@ class TrainGraph:
         self.directed = bool(directed)               # network_type = 1: rows list successors only (nx.DiGraph)
         self.hub_index = self.hub_bits = None        # hub bit matrix (build_hub_matrix): hub x hub adjacency in one load
 
-    HUB_DEGREES = (128, 256)                         # neighbour lists longer than hub_degree are not streamed by the extraction:
-    MAX_HUBS = 4096                                  # the smallest of these that leaves at most MAX_HUBS hubs (2 MB of bits)
-    hub_degree = 256                                 # (until build_hub_matrix chose; 128: 0.47 -> 0.34 ms per 100 K collab-shaped pairs)
+    # neighbour lists longer than hub_degree are not streamed by the extraction; their nodes get rows in the hub bit matrix.
+    # build_hub_matrix takes the smallest candidate that leaves at most MAX_HUBS hubs (8 MB of bits).  100 K pairs on the
+    # collab-shaped graph (profiles/r02/seal_hub_degree.log): 256 (988 hubs) 0.46 ms, 128 (4048) 0.32, 64 (5574) 0.32,
+    # 32 (12.7 K) 0.34 -- the graph has ~3000 nodes of degree 150-200 whose lists were streamed in every heavy pair
+    HUB_DEGREES = (64, 128, 256)
+    MAX_HUBS = 8192
+    hub_degree = 256                                 # (until build_hub_matrix chose)
 
     def build_hub_matrix(self):
         """hub_index[node] = row in the bit matrix (-1: not a hub), hub_bits[row, c >> 5] bit (c & 31) = hubs row and c
