@@ -63,10 +63,12 @@ class TrainGraph:
         cols = idx[self.col[starts + offs].long()].long()
         keep = cols >= 0
         dense[rows[keep], cols[keep]] = True
-        weights = (torch.ones(32, dtype=torch.int64, device=dev) << torch.arange(32, device=dev))
-        words = (dense.view(H, W, 32).to(torch.int64) * weights).sum(-1)
+        # 32 columns -> one little-endian word: byte b of a word holds columns 8 b .. 8 b + 7 (uint8 arithmetic: the
+        # int64 form took H^2 x 8 bytes of temporaries, 250 MB at 5.6 K hubs)
+        w8 = (torch.ones(8, dtype=torch.uint8, device=dev) << torch.arange(8, dtype=torch.uint8, device=dev))
+        byts = (dense.view(H, W, 4, 8).to(torch.uint8) * w8).sum(-1, dtype=torch.uint8)
         self.hub_index = idx
-        self.hub_bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()   # uint32 bit patterns
+        self.hub_bits = byts.contiguous().view(torch.int32).view(H, W)   # uint32 bit patterns
         self.hub_words = W
         return self
 
