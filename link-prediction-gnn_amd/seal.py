@@ -31,11 +31,13 @@ class TrainGraph:
         self.hub_index = self.hub_bits = None        # hub bit matrix (build_hub_matrix): hub x hub adjacency in one load
 
     # neighbour lists longer than hub_degree are not streamed by the extraction; their nodes get rows in the hub bit matrix.
-    # build_hub_matrix takes the smallest candidate that leaves at most MAX_HUBS hubs (8 MB of bits).  100 K pairs on the
-    # collab-shaped graph (profiles/r02/seal_hub_degree.log): 256 (988 hubs) 0.46 ms, 128 (4048) 0.32, 64 (5574) 0.32,
-    # 32 (12.7 K) 0.34 -- the graph has ~3000 nodes of degree 150-200 whose lists were streamed in every heavy pair
-    HUB_DEGREES = (64, 128, 256)
-    MAX_HUBS = 8192
+    # build_hub_matrix takes the smallest candidate that leaves at most MAX_HUBS hubs (512 MB of bits at most).  100 K pairs
+    # on the collab-shaped graph (profiles/r02/seal_hub_degree.log): 256 (988 hubs) 0.46 ms, 128 (4048) 0.32, 64 (5574)
+    # 0.32, 32 (12.7 K) 0.34 -- the graph has ~3000 nodes of degree 150-200 whose lists were streamed in every heavy pair.
+    # ppa-shaped (mean degree 105; profiles/r02/seal_ppa_extract.log), 50 K pairs: no matrix (round 1's limit of 4096
+    # hubs) 2.94 ms; 128 (61.7 K hubs, 476 MB) 1.11; 256 (35 K, 153 MB) 1.06; 1024 (6 K) 2.41
+    HUB_DEGREES = (64, 128, 256, 512, 1024, 2048, 4096)
+    MAX_HUBS = 1 << 16
     hub_degree = 256                                 # (until build_hub_matrix chose)
 
     def build_hub_matrix(self):
@@ -55,20 +57,23 @@ class TrainGraph:
         idx = torch.full((self.n_nodes,), -1, dtype=torch.int32, device=dev)
         idx[hubs] = torch.arange(H, dtype=torch.int32, device=dev)
         W = (H + 31) // 32
-        dense = torch.zeros((H, W * 32), dtype=torch.bool, device=dev)
         lens = deg[hubs]
         rows = torch.repeat_interleave(torch.arange(H, device=dev), lens)
         starts = torch.repeat_interleave(self.rowptr[hubs], lens)
         offs = torch.arange(int(lens.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
         cols = idx[self.col[starts + offs].long()].long()
         keep = cols >= 0
-        dense[rows[keep], cols[keep]] = True
-        # 32 columns -> one little-endian word: byte b of a word holds columns 8 b .. 8 b + 7 (uint8 arithmetic: the
-        # int64 form took H^2 x 8 bytes of temporaries, 250 MB at 5.6 K hubs)
-        w8 = (torch.ones(8, dtype=torch.uint8, device=dev) << torch.arange(8, dtype=torch.uint8, device=dev))
-        byts = (dense.view(H, W, 4, 8).to(torch.uint8) * w8).sum(-1, dtype=torch.uint8)
+        rows, cols = rows[keep], cols[keep]
+        # one bit per hub x hub entry, added into int64 words (H x W x 8 bytes; a dense H x H boolean image took
+        # 1.2 GB at the ppa-shaped graph's 35 K hubs).  A repeated entry of a sorted list is adjacent: dropped first.
+        if rows.numel() > 1:
+            first = torch.ones_like(rows, dtype=torch.bool)
+            first[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
+            rows, cols = rows[first], cols[first]
+        words = torch.zeros(H * W, dtype=torch.int64, device=dev)
+        words.scatter_add_(0, rows * W + (cols >> 5), torch.ones_like(cols) << (cols & 31))
         self.hub_index = idx
-        self.hub_bits = byts.contiguous().view(torch.int32).view(H, W)   # uint32 bit patterns
+        self.hub_bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).view(H, W).contiguous()   # uint32 bit patterns
         self.hub_words = W
         return self
 
