@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The collab-shaped SEAL scoring forward as bench.py runs it (extraction, the score stack, the dense layers:
+"""The SEAL scoring forward on the ppa-shaped graph of BASELINE configs[3] (|V| = 576 289, 30.3 M undirected edges, d = 58 padded to 64, 50 K candidates) as bench.py runs the collab-shaped one (extraction, the score stack, the dense layers:
 no host read inside a forward), wall time per forward next to the sum of the stages timed alone (profiles/seal_stages.py).  Under
 rocprofv3 --kernel-trace the trace shows the gaps between the kernels of one forward."""
 import os, sys, time, torch
@@ -8,8 +8,8 @@ sys.path.insert(0, ROOT)
 import bench
 from lpgnn_amd import seal
 dev = torch.device("cuda:0")
-N, E, B, D, k = 235_868, 1_285_465, 100_000, 128, 18
-ei = bench.rmat_edges(N, E, 1, dev)
+N, E, B, D, k = 576_289, 30_326_273, 50_000, 64, 18
+ei = bench.rmat_edges(N, E, 3, dev)
 graph = seal.build_train_csr(ei.t().contiguous(), N, test_ratio=0.0, device=dev)
 gen = torch.Generator(device=dev); gen.manual_seed(2)
 pairs = torch.randint(0, N, (B, 2), generator=gen, device=dev)
