@@ -298,14 +298,16 @@ __device__ __forceinline__ void wave_pair(
       tag = 1 + (d0 < d1 ? d0 : d1) + dv2 * (dv2 + md - 1);
     }
   }
-  tags_out[b * MAXN + lane] = tag;
-  tags_out[b * MAXN + 64 + lane] = -1;
-  nodes_out[b * MAXN + lane] = nd;
-  nodes_out[b * MAXN + 64 + lane] = -1;
+  __builtin_nontemporal_store(tag, tags_out + b * MAXN + lane);
+  __builtin_nontemporal_store(-1, tags_out + b * MAXN + 64 + lane);
+  __builtin_nontemporal_store(nd, nodes_out + b * MAXN + lane);
+  __builtin_nontemporal_store(-1, nodes_out + b * MAXN + 64 + lane);
   if (tag_present && tag >= 0) tag_present[tag] = 1;
-  uint4* ao = reinterpret_cast<uint4*>(adj_out + b * MAXN * WORDS);
-  ao[lane] = make_uint4(static_cast<uint32_t>(row), static_cast<uint32_t>(row >> 32), 0u, 0u);
-  ao[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+  using u4 = __attribute__((ext_vector_type(4))) uint32_t;
+  u4* ao = reinterpret_cast<u4*>(adj_out + b * MAXN * WORDS);
+  const u4 r4 = {static_cast<uint32_t>(row), static_cast<uint32_t>(row >> 32), 0u, 0u}, z4 = {0u, 0u, 0u, 0u};
+  __builtin_nontemporal_store(r4, ao + lane);
+  __builtin_nontemporal_store(z4, ao + 64 + lane);
   if (lane == 0) { n_out[b] = n; capped_out[b] = 0; }
 }
 
