@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlock, (NT == 4 && PG == 16) ? 1 : 2) void linear_
         const T* src = Xs + r * TLD + c;
         T* dst = y + row * ldy + col;
         if (y_vec && col + EPB <= m) {
-          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+          store_stream_u4(dst, *reinterpret_cast<const uint4*>(src));
         } else {
 #pragma unroll
           for (int e = 0; e < EPB; ++e)
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kBlock3, 1) void linear_wres3_kernel(
           const T* src = Os + rr * LDO + c;
           T* dst = y + row * ldy + col;
           if (y_vec && col + EPB <= m) {
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+            store_stream_u4(dst, *reinterpret_cast<const uint4*>(src));
           } else {
 #pragma unroll
             for (int e = 0; e < EPB; ++e)

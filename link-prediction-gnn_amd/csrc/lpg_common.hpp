@@ -102,6 +102,11 @@ int seal_conv2_f32(const int64_t* node_off, const int32_t* first, int64_t n_wind
 // streaming 16-byte store (global_store_dwordx4 ... nt): for outputs much larger than the caches a pure write stream
 // runs at 5.3 TB/s instead of 4.1 (embedding, n = 5 M x 128 floats); the line still stays in the XCD's L2 for a
 // consumer that comes right after (MI355X guide, "stores of each flavour")
+__device__ __forceinline__ void store_stream_u4(void* p, uint4 v) {
+  using u4 = __attribute__((ext_vector_type(4))) uint32_t;
+  const u4 q = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(q, reinterpret_cast<u4*>(p));
+}
 __device__ __forceinline__ void store_stream(float* p, float4 v) {
   using f4 = __attribute__((ext_vector_type(4))) float;
   f4 q = {v.x, v.y, v.z, v.w};
