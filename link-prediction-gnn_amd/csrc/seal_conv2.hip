@@ -546,14 +546,15 @@ int launch_conv2(const int64_t* node_off, const int32_t* first, int64_t n_window
                  int64_t ldh, const TIN* w2, const TIN* w3, const TIN* w4, TIN* cat, int64_t ldc, float* key,
                  const float* head_k1, float* head_a16, const ConvFuse& fx, hipStream_t st, int64_t n_subgraphs = 0) {
   // n_windows >= 0: known on the host; < 0: ceil(node_off[n_subgraphs] / 128), read on the device (no host sync between
-  // the extraction and this launch).  Either way a bounded grid walks the windows: two workgroups fit a CU, and four
-  // per CU keep the tail short while the weight fragments are still staged ~5 times less often than once per window.
+  // the extraction and this launch).  Either way a bounded grid walks the windows: the weight fragments are staged once
+  // per workgroup instead of once per window.
   const int64_t upper = n_windows >= 0 ? n_windows : n_subgraphs + 1;          // a subgraph has <= 128 rows
-  // four workgroups per resident slot: the hardware dispatcher still balances windows of different cost (a grid of exactly
-  // the resident slots waits for its unluckiest member; 1.33 x the slots runs a second, mostly empty round: bf16 0.44 -> 0.64 ms)
+  // eight workgroups per resident slot: the hardware dispatcher still balances windows of different cost (a grid of exactly
+  // the resident slots waits for its unluckiest member; 1.33 x the slots runs a second, mostly empty round: bf16 0.44 -> 0.64 ms;
+  // 4 x / 8 x / 16 x the slots: fused bf16 stack 0.470 / 0.458 / 0.475 ms, fp32 0.700 / 0.681 / 0.696)
   static const int64_t slots_cat = resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, true>));
   static const int64_t slots = resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, false>));
-  const int64_t cap = 4 * (cat ? slots_cat : slots);
+  const int64_t cap = 8 * (cat ? slots_cat : slots);
   const int64_t g = upper < cap ? (upper < 1 ? 1 : upper) : cap;
   const dim3 grid(static_cast<unsigned>(g)), blk(kConvBlock);
   const int64_t* total_ptr = n_windows >= 0 ? nullptr : node_off + n_subgraphs;
