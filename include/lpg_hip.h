@@ -46,7 +46,7 @@ int lpg_abi_version(void);
 /* Kernel-selection options (csrc/options.hip; build-defined, no reference line): a process-wide table the launch
  * paths read with plain loads -- the library never calls getenv on a launch path, and a release build never reads
  * the environment at all.  Every value a release build accepts selects between variants that all return correct
- * results (the tests pin each to the oracle): "spmm_chunk", "spmm_mode" (0 / 1), "spmm_lds", "spmm_block",
+ * results (the tests pin each to the oracle): "spmm_chunk", "spmm_mode" (0 / 1), "spmm_lds", "spmm_block" (0 automatic, 64 / 128 / 256),
  * "spmm_off32", "spmm_rows_max", "spmm_rows_ecap", "spmm_no_edge", "spmm_fill_overlap" (1: big graphs fill
  * their edge-less rows on a library-owned second stream beside the main kernel, joined before the call's work on the
  * caller's stream ends; never inside a stream capture), "seal_conv_fp32", "gn_small",

@@ -24,7 +24,7 @@ struct Options {
   int64_t spmm_chunk = 0;        // edges per SpMM chunk (multiple of 16); 0 = automatic (chunk_for)
   int64_t spmm_mode = 0;         // 0 default; 1 index-prefetch variant; 2 gather-only (LPG_TUNING builds only)
   int64_t spmm_lds = -1;         // LDS bytes reserved per workgroup (occupancy limiter); -1 = automatic
-  int64_t spmm_block = kBlock;   // threads per workgroup: 64 / 128 / 256
+  int64_t spmm_block = 0;        // threads per SpMM workgroup: 0 automatic, or 64 / 128 / 256
   int64_t spmm_off32 = 1;        // 32-bit gather offsets when X spans < 4 GiB
   int64_t spmm_rows_max = 32;    // longest row for which the row-parallel one-launch SpMM is taken (0 disables)
   int64_t spmm_rows_ecap = int64_t(1) << 21;

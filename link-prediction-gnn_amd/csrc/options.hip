@@ -25,7 +25,7 @@ const Entry kEntries[] = {
     {"spmm_mode", &Options::spmm_mode, 0, 1},
 #endif
     {"spmm_lds", &Options::spmm_lds, -1, 160 * 1024},
-    {"spmm_block", &Options::spmm_block, 64, 256},
+    {"spmm_block", &Options::spmm_block, 0, 256},
     {"spmm_off32", &Options::spmm_off32, 0, 1},
     {"spmm_rows_max", &Options::spmm_rows_max, 0, 1 << 20},
     {"spmm_rows_ecap", &Options::spmm_rows_ecap, 0, int64_t(1) << 40},

@@ -40,8 +40,8 @@ struct Tune {
     mode = static_cast<int>(o.spmm_mode);
     lds = static_cast<int>(o.spmm_lds);
     off32 = static_cast<int>(o.spmm_off32);
-    block = static_cast<int>(o.spmm_block);
-    if (block != 64 && block != 128 && block != 256) block = kBlock;
+    block = static_cast<int>(o.spmm_block);               // 0 = automatic (launch_g)
+    if (block != 0 && block != 64 && block != 128 && block != 256) block = 0;
   }
 };
 inline Tune tune() { return Tune(); }
@@ -692,19 +692,27 @@ int launch_g(const SpmmArgs& a, int64_t e_cap, hipStream_t st) {
   // 6.17 (1/CU: the bf16 widen leaves too little overlap with one wave per SIMD).  Reserving LDS
   // per workgroup admits exactly that many: > 80 KiB -> one, 64 KiB -> two of the CU's 160 KiB.
   // Small graphs are latency bound and keep the default.
-  int lds = tn.lds;
+  // Round 2: at the same number of waves per CU, 64-thread workgroups beat one or two 256-thread ones (a wave that has
+  // finished its chunks frees its slot instead of waiting for three siblings): fp32 d = 128 four waves per CU 8.31 ->
+  // 8.01 ms, d = 256 33.7 -> 33.3, bf16 d = 256 20.8 -> 19.7; fp32 d = 64 six waves per CU 4.02 -> 3.89 (bf16 d = 128 and
+  // narrower rows: no change) -- same-box sweeps of spmm_lds / spmm_block.
+  int lds = tn.lds, block = tn.block ? tn.block : kBlock;
   if (lds < 0) {
     lds = 0;
     // ... only where the gathers actually go to HBM: X must be much larger than the 256 MB Infinity Cache.
     // A block-diagonal batch of SEAL subgraphs (X = 187 MB, every gather lands in its own subgraph's few
     // KB) is L2-latency bound instead and wants every wave it can get: 3.4 -> 1.9 ms for the 4-layer stack.
     const int64_t x_bytes = a.n_cols * a.ldx * static_cast<int64_t>(sizeof(T));
-    if (e_cap >= (int64_t(1) << 20) && x_bytes >= (int64_t(384) << 20))
-      lds = (sizeof(T) == 4 && G * VEC * sizeof(T) >= 512) ? 90000 : 65536;
+    if (e_cap >= (int64_t(1) << 20) && x_bytes >= (int64_t(384) << 20)) {
+      constexpr int tile_bytes = G * VEC * static_cast<int>(sizeof(T));     // bytes of an X row one group gathers
+      if (tn.block == 0 && tile_bytes >= 512) { block = 64; lds = 40960; }             // four waves per CU
+      else if (tn.block == 0 && tile_bytes >= 256) { block = 64; lds = 26000; }        // six
+      else lds = (sizeof(T) == 4 && tile_bytes >= 512) ? 90000 : 65536;                // (a forced block size: the 256-thread limits)
+    }
   }
   const int64_t n_waves = ceil_div(n_chunks, GPW);
-  const int64_t n_blocks = ceil_div(n_waves, tn.block / kWave);
-  const dim3 blk(tn.block);
+  const int64_t n_blocks = ceil_div(n_waves, block / kWave);
+  const dim3 blk(block);
   const int64_t tiles = ceil_div(a.d, G * VEC);
   LPG_REQUIRE(n_blocks < (int64_t(1) << 31) && tiles < 65536, "csr_spmm: grid too large");
   dim3 grid(static_cast<unsigned>(n_blocks), static_cast<unsigned>(tiles));
