@@ -274,7 +274,8 @@ int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C
 /* The whole small-graph scoring forward of LocalWLNet (TwoWL/model/model.py:68-84; the timed call of
  * TwoWL/model/train.py:54-60) as ONE call: `block` (HOST memory, n_words int64 words) lists the forward's launches in
  * order as { op, a_0 .. a_{k-1} } -- op 1: lpg_embedding_graphnorm_f32 (k = 12), 2: lpg_small_linear_t_f32 (27),
- * 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23), 5: lpg_small_gcn_embed_f32 (21); a_i = that entry point's i-th argument (pointers and
+ * 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23), 5: lpg_small_gcn_embed_f32 (21), 6: lpg_tuple_layer_f32 (29),
+ * 7: lpg_tuple_readout_f32 (30); a_i = that entry point's i-th argument (pointers and
  * integers as they are, `float eps` as the bit pattern of a double; the trailing stream argument is left out).  Every
  * launch goes through the same entry point as the one-by-one path and is enqueued on `stream`: same kernels, same
  * results, one host call per forward instead of six (the forward is launch-bound: 205 -> ~60 us eager).
@@ -305,6 +306,72 @@ int64_t lpg_compact_cols_bytes(int64_t E);
 int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8_t* keep,
                          int64_t* out, void* workspace, int64_t workspace_bytes,
                          int64_t* count_host, void* stream);
+
+/* ---------------------------------------------------------------- 2-WL aggregation WITHOUT the tuple graph (a7, f1)
+ * TwoWL/utils.py:36-45 (get_ei2) links every graph tuple ending at node i with every tuple starting at i, :48-50
+ * (blockei2) drops the edges of blocked source tuples, :71-78 (reverse) makes the two orientations the model convolves
+ * over (TwoWL/model/model.py:76-77).  Every per-node block is complete bipartite and -- with pos_edge in double()'s
+ * layout (:81-90) and blocked ids in partner pairs (TwoWL/model/train.py:26) -- all its sources share one degree, so
+ * GCNConv over either orientation is a per-node sum over the MEMBER tuples (graph tuples that are not blocked) and a
+ * broadcast; E2 = sum deg^2 edges are never built (csrc/tuple_wl.hip; fp64 restatement and proof-by-test:
+ * oracle/aggregation.py localwl_forward_collapsed).  Tuple b = column b of cat(pos_edge, pred_edge); node_a(b) =
+ * start(b), node_r(b) = start(b ^ 1); Q = the non-member tuples (candidates + blocked), numbered in tuple order.
+ *
+ * lpg_tuple_plan_build (once per tuple graph; pos_edge [2,E1], pred_edge [2,Ep] int64 row-major, E1 and Ep even;
+ *   blocked: uint8 [E1] or NULL; rowptr: the member adjacency's CSR row pointer, int64 [n_node+1]):
+ *   cnt[i] = members starting at i; qpos[b] = position of b among the non-members or -1; qinfo[q] = (start, end,
+ *   node_r, b) for q < q_cap; optional tnode[b] = (node_a, node_r) and seg_a / seg_r [E1] = the member's start / end
+ *   node, n_node for a non-member (scatter indices of the operator form); head (int32[4], device): [0] = Q,
+ *   [1] = bit 0: layout conditions violated (use the explicit tuple graph), bit 1: a node id out of range (also
+ *   err_flag).  No host sync.
+ * lpg_tuple_layer_f32: one 2-WL layer, both orientations (C <= 32).  mode 1 (first layer): x = the 1-WL output
+ *   [n_node, C] (model.py:73; with in_part != NULL still un-normalised: GraphNorm (+ ReLU) of the small-graph conv1
+ *   is applied on load, part layout [in_rb][2][C]), ax = A x [n_node, C] or NULL = summed inside from (rowptr, col);
+ *   the pair product (model.py:75) never exists for member tuples: their group sum is x[i] * (A x)[i].  mode 2:
+ *   x = (F_a | F_r) [n_node, 2C] from lpg_tuple_apply_f32, ax = A x [n_node, 2C], hq_prev [Q, C].
+ *   Writes t_node [n_node, 2C] = (T_a | T_r) (may be NULL), y_q [Q, 2C] = the non-member rows (bias added) and
+ *   part [n_blocks][2][64] (fp64 sums of y and y^2 over ALL P rows, column = orientation * 32 + c), n_blocks =
+ *   lpg_tuple_layer_blocks(n_node, Q).  Atomic-free, fixed order.
+ * lpg_tuple_fold_f64: part [n_in][2][64] -> out [n_out][2][64] (consumers take at most 64 partial blocks).
+ * lpg_tuple_apply_f32: GraphNorm + ReLU between two layers: ff [n_node, 2C], hq [Q, C] = f_a(y_a) + f_r(y_r).
+ * lpg_tuple_readout_f32: model.py:78-83 with the last layer's GraphNorm + ReLU applied on load; idx may name any
+ *   tuple (member rows are F_a[start] + F_r[end]).
+ * lpg_tuple_bcast_f32: the broadcast of the operator form -- GCNConv(x, orientation) for an arbitrary [P, C] input:
+ *   y[b] = t_node[node(b)] / cnt + bias (member), t_node[node(b)] / sqrt(cnt (cnt + 1)) + hq[q] / (cnt + 1) + bias
+ *   (otherwise); t_node = (group sums of x over the members) W^T, hq = x[non-members] W^T. */
+int64_t lpg_tuple_plan_bytes(int64_t P);
+int lpg_tuple_plan_build(const int64_t* pos_edge, int64_t E1, const int64_t* pred_edge, int64_t Ep,
+                         int64_t n_node, const uint8_t* blocked, const int64_t* rowptr, int32_t* cnt,
+                         int32_t* qpos, int32_t* qinfo, int64_t q_cap, int32_t* tnode, int64_t* seg_a,
+                         int64_t* seg_r, int32_t* head, void* workspace, int64_t workspace_bytes,
+                         int32_t* err_flag, void* stream);
+int64_t lpg_tuple_layer_blocks(int64_t n_node, int64_t Q);
+int lpg_tuple_layer_f32(int mode, int64_t n_node, int64_t Q, int64_t C, const float* x, int64_t ldx,
+                        const float* ax, int64_t ldax, const int64_t* rowptr, const int32_t* col,
+                        const float* hq_prev, const int32_t* cnt, const int32_t* qinfo,
+                        const float* w_a, const float* w_r, const float* b_a, const float* b_r,
+                        float* t_node, float* y_q, double* part, int64_t n_blocks,
+                        const double* in_part, const float* in_gw, const float* in_gb,
+                        const float* in_gms, int64_t in_rb, int in_relu, int64_t in_n, float in_eps,
+                        void* stream);
+int lpg_tuple_fold_f64(const double* part, int64_t n_in, double* out, int64_t n_out, void* stream);
+int lpg_tuple_apply_f32(int64_t n_node, int64_t Q, int64_t C, const float* t_node, const float* y_q,
+                        const int32_t* cnt, const double* part, int64_t n_part, int64_t n_rows,
+                        const float* gw_a, const float* gb_a, const float* gms_a, float eps_a,
+                        int relu_a, const float* gw_r, const float* gb_r, const float* gms_r,
+                        float eps_r, int relu_r, const float* b_a, const float* b_r, float* ff,
+                        float* hq, void* stream);
+int lpg_tuple_readout_f32(int64_t n_node, int64_t Q, int64_t C, int64_t E1, int64_t P,
+                          const int64_t* pos_edge, const float* t_node, const float* y_q,
+                          const int32_t* cnt, const int32_t* qpos, const double* part, int64_t n_part,
+                          const float* gw_a, const float* gb_a, const float* gms_a, float eps_a,
+                          int relu_a, const float* gw_r, const float* gb_r, const float* gms_r,
+                          float eps_r, int relu_r, const float* b_a, const float* b_r,
+                          const int64_t* idx, int64_t B, const float* w, const float* b0, float* out,
+                          int32_t* err_flag, void* stream);
+int lpg_tuple_bcast_f32(int64_t P, int64_t C, int orient, const int32_t* tnode, const int32_t* cnt,
+                        const int32_t* qpos, const float* t_node, int64_t ldt, const float* hq,
+                        int64_t ldh, const float* bias, float* y, int64_t ldy, void* stream);
 
 /* The same graph for ANY size: both directions of every pair become a 64-bit key row * n_nodes + col, the keys are
  * radix-sorted over their significant bits and deduplicated (rocPRIM), and one kernel emits col (ascending, unique

@@ -1,0 +1,560 @@
+// The 2-WL aggregation of LocalWLNet WITHOUT the tuple graph (TwoWL/utils.py:36-50,71-78 -> TwoWL/model/model.py:75-83).
+//
+// get_ei2 links, for every node i, every graph tuple ENDING at i with every tuple STARTING at i: a complete bipartite
+// block per node, E2 = sum_i indeg(i) * outdeg(i) edges.  With pos_edge in double()'s layout (columns 2k / 2k + 1 are
+// the two directions of one edge; blocked ids come in such pairs, TwoWL/model/train.py:26) the two orientations that
+// reverse() makes of it have, for a destination tuple b,
+//     orientation a: in-neighbours = the MEMBER tuples (graph tuples that are not blocked) starting at node_a(b) = start(b)
+//     orientation r: in-neighbours = the members ending at node_r(b) = start(b ^ 1)   (= end(b) for doubled candidates)
+// plus, through add_remaining_self_loops, b itself exactly when b is not a member; and all members of one group have the
+// same degree cnt(node).  So GCNConv over either orientation is a per-node sum over the members and a broadcast:
+//     y[b] = T[node(b)] / cnt + bias                                        b member
+//     y[b] = T[node(b)] / sqrt(cnt (cnt + 1)) + (h[b] W^T) / (cnt + 1) + bias   otherwise  (first term 0 when cnt = 0)
+// with T[i] = (sum of h over the group of i) W^T.  Members' features are node-level themselves -- x[u] * x[v] in front of
+// the first layer, F_a[start] + F_r[end] after one -- so the group sums are products with the member adjacency A
+// (sum_{t: i -> w} x[i] x[w] = x[i] * (A x)[i]), and a whole layer costs O((N + Q) C^2 + E1 C) instead of O(E2 C)
+// (Q = non-member tuples: the candidates, and blocked graph tuples).  GraphNorm's column statistics over all P rows are
+// sum_i cnt(i) M[i] + sum_q y[q]: never a pass over P rows either.  fp64 restatement: oracle/aggregation.py
+// (localwl_forward_collapsed), equal to the explicit path to 1e-10 on random graphs with loops, duplicates and blocking.
+//
+// Kernels (lanes 0-31 = columns of orientation a, 32-63 = orientation r; C <= 32, every reference configuration):
+//   tw_layer_kernel   a wave per node row / non-member row: builds the row's input vector per orientation, multiplies it
+//                     by W (rows of W in registers, the vector broadcast from a wave-private LDS slot), writes T / y and
+//                     fp64 column-sum partials per workgroup (fixed order: reproducible);
+//   tw_fold_kernel    many partial blocks -> 16;   tw_apply_kernel  GraphNorm + ReLU between two layers;
+//   tw_readout_kernel model.py:78-83 with the last layer's GraphNorm applied on load;
+//   tw_bcast_kernel   the broadcast half of the operator form (GCNConv(x, orientation) on arbitrary [P, C] input).
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "lpg_common.hpp"
+
+namespace lpg {
+namespace {
+
+constexpr int kTwBlock = 1024;             // 16 waves that never synchronise before the final fold of their sums
+constexpr int kTwWaves = kTwBlock / kWave;
+constexpr int kTwMaxBlocks = 1024;
+constexpr int kTwMaxPart = 64;             // partial blocks a consumer folds by itself
+
+struct FlagToI32 {
+  __host__ __device__ int32_t operator()(uint8_t v) const { return v ? 1 : 0; }
+};
+
+// ------------------------------------------------------------------------------------------------ plan
+__global__ __launch_bounds__(kBlock) void tw_plan_flags_kernel(const int64_t* __restrict__ pos_edge, int64_t E1,
+                                                               const int64_t* __restrict__ pred_edge, int64_t Ep,
+                                                               int64_t n_node, const uint8_t* __restrict__ blocked,
+                                                               const int64_t* __restrict__ rowptr, int32_t* __restrict__ cnt,
+                                                               uint8_t* __restrict__ flags, int32_t* head, int32_t* err_flag) {
+  const int64_t P = E1 + Ep, work = P > n_node ? P : n_node;
+  for (int64_t b = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; b < work;
+       b += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    if (b < n_node) cnt[b] = static_cast<int32_t>(rowptr[b + 1] - rowptr[b]);
+    if (b >= P) continue;
+    const int64_t s = b < E1 ? pos_edge[b] : pred_edge[b - E1];
+    const int64_t e = b < E1 ? pos_edge[E1 + b] : pred_edge[Ep + b - E1];
+    if (s < 0 || s >= n_node || e < 0 || e >= n_node) {
+      flag_error(err_flag, LPG_F_INDEX_RANGE);
+      atomicOr(head + 1, 2);
+    }
+    bool member = b < E1;
+    if (b < E1) {
+      const int64_t p = b ^ 1;
+      if (pos_edge[p] != e || pos_edge[E1 + p] != s) atomicOr(head + 1, 1);          // not double()'s layout
+      if (blocked) {
+        if ((blocked[b] != 0) != (blocked[p] != 0)) atomicOr(head + 1, 1);           // one direction blocked only
+        member = blocked[b] == 0;
+      }
+    }
+    flags[b] = member ? 0 : 1;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void tw_plan_fill_kernel(const int64_t* __restrict__ pos_edge, int64_t E1,
+                                                              const int64_t* __restrict__ pred_edge, int64_t Ep,
+                                                              int64_t n_node, const uint8_t* __restrict__ flags, int scanned,
+                                                              int32_t* __restrict__ qpos, int32_t* __restrict__ qinfo,
+                                                              int64_t q_cap, int32_t* __restrict__ tnode,
+                                                              int64_t* __restrict__ seg_a, int64_t* __restrict__ seg_r,
+                                                              int32_t* head) {
+  const int64_t P = E1 + Ep;
+  auto start_of = [&](int64_t t) { return t < E1 ? pos_edge[t] : pred_edge[t - E1]; };
+  auto clampn = [&](int64_t v) { return v < 0 ? int64_t(0) : (v >= n_node ? n_node - 1 : v); };
+  for (int64_t b = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; b < P;
+       b += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t s = clampn(start_of(b));
+    const int64_t e = clampn(b < E1 ? pos_edge[E1 + b] : pred_edge[Ep + b - E1]);
+    const int64_t nr = clampn(start_of(b ^ 1));                     // P is even (checked by the entry point)
+    const bool non = flags[b] != 0;
+    const int32_t q = scanned ? qpos[b] : static_cast<int32_t>(b - E1);
+    if (tnode) {
+      tnode[2 * b] = static_cast<int32_t>(s);
+      tnode[2 * b + 1] = static_cast<int32_t>(nr);
+    }
+    if (b < E1) {
+      if (seg_a) seg_a[b] = non ? n_node : s;
+      if (seg_r) seg_r[b] = non ? n_node : e;
+    }
+    if (non) {
+      if (q < q_cap) {
+        int32_t* o = qinfo + 4 * static_cast<int64_t>(q);
+        o[0] = static_cast<int32_t>(s);
+        o[1] = static_cast<int32_t>(e);
+        o[2] = static_cast<int32_t>(nr);
+        o[3] = static_cast<int32_t>(b);
+      }
+      qpos[b] = q;
+    } else {
+      qpos[b] = -1;
+    }
+    if (b == P - 1) head[0] = scanned ? q + (non ? 1 : 0) : static_cast<int32_t>(Ep);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GraphNorm on load
+struct TwCoef {
+  float sh, sc, bi;
+  int relu;
+};
+__device__ __forceinline__ float tw_apply(const TwCoef& c, float y) {
+  const float o = (y - c.sh) * c.sc + c.bi;
+  return (c.relu && o < 0.f) ? 0.f : o;
+}
+// torch_geometric.nn.GraphNorm (batch=None) [3P, TwoWL/model/model.py:38]: o = x - mean * mean_scale;
+// y = weight * o / sqrt(mean(o^2) + eps) + bias; one-pass variance in fp64 (the formula of small_graph.hip's sg_coef)
+__device__ __forceinline__ TwCoef tw_coef_from_sums(double s, double s2, double n, float gw, float gb, float gms, float eps,
+                                                    int relu) {
+  const double mean = s / n, ex2 = s2 / n, ms = static_cast<double>(gms);
+  double var = ex2 - mean * mean * ms * (2.0 - ms);
+  if (var < 0.0) var = 0.0;
+  const double inv = 1.0 / sqrt(var + static_cast<double>(eps));
+  return TwCoef{static_cast<float>(mean * ms), static_cast<float>(static_cast<double>(gw) * inv), gb, relu};
+}
+
+struct TwNorm {          // statistics of one 2-WL layer: part [n_part][2][64] (column = side * 32 + c), P rows
+  const double* part;
+  const float *gw_a, *gb_a, *gms_a, *gw_r, *gb_r, *gms_r;
+  double n_rows;
+  float eps_a, eps_r;
+  int n_part, relu_a, relu_r;
+};
+__device__ __forceinline__ TwCoef tw_coef(const TwNorm& nm, int side, int c) {
+  const int col = side * 32 + c;
+  double s = 0.0, s2 = 0.0;
+#pragma unroll 4
+  for (int g = 0; g < nm.n_part; ++g) {                        // fixed order
+    s += nm.part[(static_cast<int64_t>(g) * 2 + 0) * 64 + col];
+    s2 += nm.part[(static_cast<int64_t>(g) * 2 + 1) * 64 + col];
+  }
+  const float* gw = side ? nm.gw_r : nm.gw_a;
+  const float* gb = side ? nm.gb_r : nm.gb_a;
+  const float* gms = side ? nm.gms_r : nm.gms_a;
+  return tw_coef_from_sums(s, s2, nm.n_rows, gw ? gw[c] : 1.f, gb ? gb[c] : 0.f, gms ? gms[c] : 1.f,
+                           side ? nm.eps_r : nm.eps_a, side ? nm.relu_r : nm.relu_a);
+}
+
+struct TwNormIn {        // deferred GraphNorm of the first layer's input (small-graph conv1: y + [rb][2][C] column sums)
+  const double* part;
+  const float *gw, *gb, *gms;
+  int rb, relu, n;
+  float eps;
+};
+__device__ __forceinline__ TwCoef tw_coef_in(const TwNormIn& nm, int C, int c) {
+  double s = 0.0, s2 = 0.0;
+  for (int b = 0; b < nm.rb; ++b) {
+    s += nm.part[(static_cast<int64_t>(b) * 2 + 0) * C + c];
+    s2 += nm.part[(static_cast<int64_t>(b) * 2 + 1) * C + c];
+  }
+  return tw_coef_from_sums(s, s2, static_cast<double>(nm.n), nm.gw ? nm.gw[c] : 1.f, nm.gb ? nm.gb[c] : 0.f,
+                           nm.gms ? nm.gms[c] : 1.f, nm.eps, nm.relu);
+}
+
+// value of a member row of node i: every member tuple of the group shares it
+__device__ __forceinline__ float tw_member(float t, int cn, float bias) { return t / static_cast<float>(cn) + bias; }
+
+// ------------------------------------------------------------------------------------------------ one 2-WL layer
+struct TwLayerArgs {
+  const float* x;        // MODE 1: x1 [n, C] (the 1-WL output, or un-normalised + nin); MODE 2: FF [n, 2C] = (F_a | F_r)
+  const float* ax;       // MODE 1: A x1 [n, C] (null with INLINE); MODE 2: A FF [n, 2C]
+  const int64_t* rowptr; // member adjacency (INLINE only)
+  const int32_t* col;
+  const float* hq_prev;  // MODE 2: the non-member rows of the previous layer [Q, C]
+  const int32_t* cnt;    // [n] members starting (= ending) at a node
+  const int32_t* qinfo;  // [Q][4] = (start, end, node_r, tuple id)
+  const float *w_a, *w_r, *b_a, *b_r;
+  float* t_node;         // [n, 2C] = (T_a | T_r), may be null
+  float* y_q;            // [Q, 2C]
+  double* part;          // [gridDim.x][2][64]
+  TwNormIn nin;
+  int64_t ldx, ldax;
+  int n_node, Q, C;
+};
+
+template <int MODE, bool INLINE, bool DEFER>
+__global__ __launch_bounds__(kTwBlock) void tw_layer_kernel(const TwLayerArgs a) {
+  __shared__ float sv[kTwWaves][64];
+  __shared__ double sred[kTwWaves][2][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int side = lane >> 5, c = lane & 31, C = a.C;
+  const bool live = c < C;
+  const int cc = live ? c : C - 1;
+  float w[32];
+  {
+    const float* wm = side ? a.w_r : a.w_a;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float v = wm[cc * C + (k < C ? k : 0)];
+      w[k] = (live && k < C) ? v : 0.f;
+    }
+  }
+  const float bias = (side ? a.b_r : a.b_a)[cc];
+  TwCoef cin{0.f, 1.f, 0.f, 0};
+  if (DEFER) cin = tw_coef_in(a.nin, C, cc);
+  auto ldx1 = [&](int64_t j) -> float {                     // element cc of row j of x1 (MODE 1)
+    const float v = a.x[j * a.ldx + cc];
+    return DEFER ? tw_apply(cin, v) : v;
+  };
+  auto row_sum = [&](int64_t node, int first, int step) -> float {      // sum over the member row of `node`, entries first, first + step, ...
+    const int64_t e0 = a.rowptr[node], e1 = a.rowptr[node + 1];
+    float acc = 0.f;
+    int64_t e = e0 + first;
+    for (; e + 3 * step < e1; e += 4 * step) {
+      const int j0 = a.col[e], j1 = a.col[e + step], j2 = a.col[e + 2 * step], j3 = a.col[e + 3 * step];
+      const float v0 = ldx1(j0), v1 = ldx1(j1), v2 = ldx1(j2), v3 = ldx1(j3);
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; e < e1; e += step) acc += ldx1(a.col[e]);
+    return acc;
+  };
+  double s1 = 0.0, s2 = 0.0;
+  const int rows = a.n_node + a.Q;
+  const int gw = blockIdx.x * kTwWaves + wv, nw = gridDim.x * kTwWaves;
+  const int own = side * C + cc, oth = (1 - side) * C + cc;
+  for (int r = gw; r < rows; r += nw) {
+    float v;
+    int cn = 0, q = -1;
+    if (r < a.n_node) {
+      cn = a.cnt[r];
+      if (MODE == 1) {
+        float axv;
+        if (INLINE) {
+          axv = row_sum(r, side, 2);                        // the two halves take alternate entries
+          axv += __shfl_xor(axv, 32);
+        } else {
+          axv = a.ax[r * a.ldax + cc];
+        }
+        v = ldx1(r) * axv;
+      } else {
+        v = static_cast<float>(cn) * a.x[r * a.ldx + own] + a.ax[r * a.ldax + oth];
+      }
+    } else {
+      q = r - a.n_node;
+      const int4 inf = *reinterpret_cast<const int4*>(a.qinfo + 4 * static_cast<int64_t>(q));
+      const int node = side ? inf.z : inf.x;
+      const int cq = a.cnt[node];
+      const float cf = static_cast<float>(cq);
+      const float ca = cq > 0 ? 1.0f / sqrtf(cf * (cf + 1.0f)) : 0.f, cb = 1.0f / (cf + 1.0f);
+      float sx, h;
+      if (MODE == 1) {
+        const float xs = ldx1(inf.x), xe = ldx1(inf.y);
+        h = xs * xe;
+        const float xn = side ? ldx1(node) : xs;
+        const float axn = INLINE ? row_sum(node, 0, 1) : a.ax[static_cast<int64_t>(node) * a.ldax + cc];
+        sx = xn * axn;
+      } else {
+        h = a.hq_prev[static_cast<int64_t>(q) * C + cc];
+        sx = cf * a.x[static_cast<int64_t>(node) * a.ldx + own] + a.ax[static_cast<int64_t>(node) * a.ldax + oth];
+      }
+      v = ca * sx + cb * h;
+    }
+    sv[wv][lane] = live ? v : 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const float4* pv = reinterpret_cast<const float4*>(&sv[wv][side * 32]);
+    float acc = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      if (4 * k4 < C) {
+        const float4 t = pv[k4];
+        acc = fmaf(t.x, w[4 * k4 + 0], acc);
+        acc = fmaf(t.y, w[4 * k4 + 1], acc);
+        acc = fmaf(t.z, w[4 * k4 + 2], acc);
+        acc = fmaf(t.w, w[4 * k4 + 3], acc);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (q < 0) {
+      if (a.t_node && live) a.t_node[static_cast<int64_t>(r) * (2 * C) + side * C + c] = acc;
+      if (cn > 0 && live) {
+        const double m = static_cast<double>(tw_member(acc, cn, bias)), cd = static_cast<double>(cn);
+        s1 += cd * m;
+        s2 += cd * m * m;
+      }
+    } else if (live) {
+      const float y = acc + bias;
+      a.y_q[static_cast<int64_t>(q) * (2 * C) + side * C + c] = y;
+      s1 += static_cast<double>(y);
+      s2 += static_cast<double>(y) * static_cast<double>(y);
+    }
+  }
+  sred[wv][0][lane] = s1;
+  sred[wv][1][lane] = s2;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kTwWaves; ++k) s += sred[k][which][ln];
+    a.part[(static_cast<int64_t>(blockIdx.x) * 2 + which) * 64 + ln] = s;
+  }
+}
+
+__global__ __launch_bounds__(128) void tw_fold_kernel(const double* __restrict__ part, int n_in, double* __restrict__ out) {
+  const int which = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  double s = 0.0;
+  for (int g = blockIdx.x; g < n_in; g += gridDim.x) s += part[(static_cast<int64_t>(g) * 2 + which) * 64 + ln];
+  out[(static_cast<int64_t>(blockIdx.x) * 2 + which) * 64 + ln] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ between two layers
+__global__ __launch_bounds__(kBlock) void tw_apply_kernel(int n_node, int Q, int C, const float* __restrict__ t_node,
+                                                          const float* __restrict__ y_q, const int32_t* __restrict__ cnt,
+                                                          const TwNorm nm, const float* __restrict__ b_a,
+                                                          const float* __restrict__ b_r, float* __restrict__ ff,
+                                                          float* __restrict__ hq) {
+  const int lane = threadIdx.x & 63;
+  const int side = lane >> 5, c = lane & 31;
+  const bool live = c < C;
+  const int cc = live ? c : C - 1;
+  const TwCoef co = tw_coef(nm, side, cc);
+  const float bias = (side ? b_r : b_a)[cc];
+  const int gw = (blockIdx.x * kBlock + threadIdx.x) >> 6, nw = (gridDim.x * kBlock) >> 6;
+  for (int r = gw; r < n_node + Q; r += nw) {
+    if (r < n_node) {
+      const int cn = cnt[r];
+      const float t = t_node[static_cast<int64_t>(r) * (2 * C) + side * C + cc];
+      const float f = cn > 0 ? tw_apply(co, tw_member(t, cn, bias)) : 0.f;
+      if (live) ff[static_cast<int64_t>(r) * (2 * C) + side * C + c] = f;
+    } else {
+      const int q = r - n_node;
+      float f = tw_apply(co, y_q[static_cast<int64_t>(q) * (2 * C) + side * C + cc]);
+      f += __shfl_xor(f, 32);
+      if (live && side == 0) hq[static_cast<int64_t>(q) * C + c] = f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ readout
+// TwoWL/model/model.py:78-83: rows idx of x = relu(GN_a(y_a)) + relu(GN_r(y_r)); out[j] = sum_c x[idx[2j]] x[idx[2j+1]] w + b0.
+// A wave per scored pair: lanes 0-31 hold the row of idx[2j], 32-63 the row of idx[2j + 1].
+__global__ __launch_bounds__(kBlock) void tw_readout_kernel(int n_node, int Q, int C, int64_t E1, int64_t P,
+                                                            const int64_t* __restrict__ pos_edge,
+                                                            const float* __restrict__ t_node, const float* __restrict__ y_q,
+                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ qpos,
+                                                            const TwNorm nm, const float* __restrict__ b_a,
+                                                            const float* __restrict__ b_r, const int64_t* __restrict__ idx,
+                                                            int B, const float* __restrict__ w, const float* __restrict__ b0,
+                                                            float* __restrict__ out, int32_t* err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int t = lane >> 5, c = lane & 31;
+  const bool live = c < C;
+  const int cc = live ? c : C - 1;
+  const TwCoef ca = tw_coef(nm, 0, cc), cr = tw_coef(nm, 1, cc);
+  const float ba = b_a[cc], br = b_r[cc], wc = live ? w[cc] : 0.f, bb = b0 ? b0[0] : 0.f;
+  const int gw = (blockIdx.x * kBlock + threadIdx.x) >> 6, nw = (gridDim.x * kBlock) >> 6;
+  for (int j = gw; j < B; j += nw) {
+    const int64_t b = idx[2 * static_cast<int64_t>(j) + t];
+    const bool bad = b < 0 || b >= P;
+    if (__ballot(bad)) {
+      if (lane == 0) flag_error(err_flag, LPG_F_INDEX_RANGE);
+      continue;
+    }
+    const int q = qpos[b];
+    float ya, yr;
+    if (q < 0) {                                             // a member: b < E1
+      const int64_t s = pos_edge[b], e = pos_edge[E1 + b];
+      ya = tw_member(t_node[s * (2 * C) + cc], cnt[s], ba);
+      yr = tw_member(t_node[e * (2 * C) + C + cc], cnt[e], br);
+    } else {
+      ya = y_q[static_cast<int64_t>(q) * (2 * C) + cc];
+      yr = y_q[static_cast<int64_t>(q) * (2 * C) + C + cc];
+    }
+    const float row = tw_apply(ca, ya) + tw_apply(cr, yr);
+    const float other = __shfl_xor(row, 32);
+    float sacc = t == 0 ? row * other * wc : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+    if (lane == 0) out[j] = sacc + bb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ operator form
+// y[b] = T[node(b)] / cnt + bias (member) | T[node(b)] / sqrt(cnt (cnt + 1)) + hq[q] / (cnt + 1) + bias (otherwise):
+// GCNConv(x, orientation) for an ARBITRARY [P, C] input x once T = (group sums of x) W^T and hq = (x[non-members]) W^T exist.
+__global__ __launch_bounds__(kBlock) void tw_bcast_kernel(int64_t P, int C, int orient, const int32_t* __restrict__ tnode,
+                                                          const int32_t* __restrict__ cnt, const int32_t* __restrict__ qpos,
+                                                          const float* __restrict__ t_node, int64_t ldt,
+                                                          const float* __restrict__ hq, int64_t ldh,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int64_t ldy) {
+  const int64_t total = P * C;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t b = i / C;
+    const int c = static_cast<int>(i - b * C);
+    const int node = tnode[2 * b + orient], cn = cnt[node], q = qpos[b];
+    const float bi = bias ? bias[c] : 0.f, t = t_node[static_cast<int64_t>(node) * ldt + c];
+    float o;
+    if (q < 0) {
+      o = tw_member(t, cn, bi);
+    } else {
+      const float cf = static_cast<float>(cn);
+      o = (cn > 0 ? t / sqrtf(cf * (cf + 1.0f)) : 0.f) + hq[static_cast<int64_t>(q) * ldh + c] / (cf + 1.0f) + bi;
+    }
+    y[b * ldy + c] = o;
+  }
+}
+
+bool make_norm(TwNorm* nm, const double* part, int64_t n_part, int64_t n_rows, const float* gw_a, const float* gb_a,
+               const float* gms_a, float eps_a, int relu_a, const float* gw_r, const float* gb_r, const float* gms_r,
+               float eps_r, int relu_r) {
+  *nm = TwNorm{part, gw_a, gb_a, gms_a, gw_r, gb_r, gms_r, static_cast<double>(n_rows), eps_a, eps_r,
+               static_cast<int>(n_part), relu_a, relu_r};
+  return part && n_part >= 1 && n_part <= kTwMaxPart && n_rows >= 1;
+}
+
+}  // namespace
+}  // namespace lpg
+
+using namespace lpg;
+
+LPG_EXPORT int64_t lpg_tuple_plan_bytes(int64_t P) {
+  if (P < 0) return LPG_E_INVALID;
+  size_t s = 0;
+  (void)rocprim::exclusive_scan(nullptr, s, rocprim::make_transform_iterator(static_cast<const uint8_t*>(nullptr), FlagToI32()),
+                                static_cast<int32_t*>(nullptr), int32_t(0), static_cast<size_t>(P + 1),
+                                rocprim::plus<int32_t>(), hipStream_t(0), false);
+  return align_up(P + 16, 256) + align_up(static_cast<int64_t>(s), 256) + 256;
+}
+
+LPG_EXPORT int lpg_tuple_plan_build(const int64_t* pos_edge, int64_t E1, const int64_t* pred_edge, int64_t Ep, int64_t n_node,
+                                    const uint8_t* blocked, const int64_t* rowptr, int32_t* cnt, int32_t* qpos, int32_t* qinfo,
+                                    int64_t q_cap, int32_t* tnode, int64_t* seg_a, int64_t* seg_r, int32_t* head,
+                                    void* workspace, int64_t workspace_bytes, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(E1 >= 0 && Ep >= 0 && n_node >= 1 && q_cap >= 0, "tuple_plan_build: bad sizes");
+  LPG_REQUIRE(E1 % 2 == 0 && Ep % 2 == 0, "tuple_plan_build: E1 and Ep must be even (tuples come in partner pairs)");
+  const int64_t P = E1 + Ep;
+  LPG_REQUIRE(P < (int64_t(1) << 31) && n_node < (int64_t(1) << 31), "tuple_plan_build: more than 2^31 tuples / nodes");
+  LPG_REQUIRE(rowptr && cnt && head && workspace && (P == 0 || (qpos && (E1 == 0 || pos_edge) && (Ep == 0 || pred_edge))) &&
+                  (q_cap == 0 || qinfo),
+              "tuple_plan_build: null pointer");
+  if (workspace_bytes < lpg_tuple_plan_bytes(P)) {
+    set_error("tuple_plan_build: workspace too small");
+    return LPG_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  LPG_HIP(hipMemsetAsync(head, 0, 16, st));
+  uint8_t* flags = static_cast<uint8_t*>(workspace);
+  void* tmp = static_cast<char*>(workspace) + align_up(P + 16, 256);
+  size_t tb = static_cast<size_t>(workspace_bytes - align_up(P + 16, 256));
+  const int64_t work = P > n_node ? P : n_node;
+  hipLaunchKernelGGL(tw_plan_flags_kernel, dim3(grid_for(work)), dim3(kBlock), 0, st, pos_edge, E1, pred_edge, Ep, n_node,
+                     blocked, rowptr, cnt, flags, head, err_flag);
+  if (P == 0) return check_launch("tuple_plan_build");
+  if (blocked)
+    LPG_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(static_cast<const uint8_t*>(flags), FlagToI32()),
+                                    qpos, int32_t(0), static_cast<size_t>(P), rocprim::plus<int32_t>(), st, false));
+  hipLaunchKernelGGL(tw_plan_fill_kernel, dim3(grid_for(P)), dim3(kBlock), 0, st, pos_edge, E1, pred_edge, Ep, n_node, flags,
+                     blocked ? 1 : 0, qpos, qinfo, q_cap, tnode, seg_a, seg_r, head);
+  return check_launch("tuple_plan_build");
+}
+
+LPG_EXPORT int64_t lpg_tuple_layer_blocks(int64_t n_node, int64_t Q) {
+  if (n_node < 0 || Q < 0) return LPG_E_INVALID;
+  const int64_t g = ceil_div(n_node + Q, kTwWaves * 2);          // two rows per wave on the reference's own graphs
+  return g < 1 ? 1 : (g > kTwMaxBlocks ? kTwMaxBlocks : g);
+}
+
+LPG_EXPORT int lpg_tuple_layer_f32(int mode, int64_t n_node, int64_t Q, int64_t C, const float* x, int64_t ldx, const float* ax,
+                                   int64_t ldax, const int64_t* rowptr, const int32_t* col, const float* hq_prev,
+                                   const int32_t* cnt, const int32_t* qinfo, const float* w_a, const float* w_r,
+                                   const float* b_a, const float* b_r, float* t_node, float* y_q, double* part,
+                                   int64_t n_blocks, const double* in_part, const float* in_gw, const float* in_gb,
+                                   const float* in_gms, int64_t in_rb, int in_relu, int64_t in_n, float in_eps, void* stream) {
+  LPG_REQUIRE((mode == 1 || mode == 2) && n_node >= 1 && Q >= 0 && C >= 1 && C <= 32 && n_node + Q < (int64_t(1) << 31),
+              "tuple_layer: needs mode 1 | 2, n_node >= 1, 1 <= C <= 32");
+  LPG_REQUIRE(x && cnt && w_a && w_r && b_a && b_r && part && (Q == 0 || (qinfo && y_q)), "tuple_layer: null pointer");
+  LPG_REQUIRE(n_blocks >= 1 && n_blocks <= kTwMaxBlocks, "tuple_layer: 1 <= n_blocks <= %d", kTwMaxBlocks);
+  LPG_REQUIRE(reinterpret_cast<uintptr_t>(qinfo) % 16 == 0, "tuple_layer: qinfo must be 16-byte aligned");
+  const bool inl = ax == nullptr, defer = in_part != nullptr;
+  LPG_REQUIRE(!inl || (mode == 1 && rowptr && col), "tuple_layer: without A x the member adjacency is needed (mode 1 only)");
+  LPG_REQUIRE(mode == 1 || (hq_prev || Q == 0), "tuple_layer: mode 2 needs the previous layer's non-member rows");
+  LPG_REQUIRE(!defer || (mode == 1 && in_rb >= 1 && in_rb <= 64 && in_n >= 1), "tuple_layer: bad deferred-norm arguments");
+  LPG_REQUIRE(ldx >= (mode == 1 ? C : 2 * C) && (inl || ldax >= (mode == 1 ? C : 2 * C)), "tuple_layer: row strides too small");
+  TwLayerArgs a{};
+  a.x = x; a.ax = ax; a.rowptr = rowptr; a.col = col; a.hq_prev = hq_prev; a.cnt = cnt; a.qinfo = qinfo;
+  a.w_a = w_a; a.w_r = w_r; a.b_a = b_a; a.b_r = b_r; a.t_node = t_node; a.y_q = y_q; a.part = part;
+  a.nin = TwNormIn{in_part, in_gw, in_gb, in_gms, static_cast<int>(in_rb), in_relu, static_cast<int>(in_n), in_eps};
+  a.ldx = ldx; a.ldax = ldax; a.n_node = static_cast<int>(n_node); a.Q = static_cast<int>(Q); a.C = static_cast<int>(C);
+  const dim3 grid(static_cast<unsigned>(n_blocks)), block(kTwBlock);
+  hipStream_t st = as_stream(stream);
+  if (mode == 2) hipLaunchKernelGGL((tw_layer_kernel<2, false, false>), grid, block, 0, st, a);
+  else if (inl && defer) hipLaunchKernelGGL((tw_layer_kernel<1, true, true>), grid, block, 0, st, a);
+  else if (inl) hipLaunchKernelGGL((tw_layer_kernel<1, true, false>), grid, block, 0, st, a);
+  else if (defer) hipLaunchKernelGGL((tw_layer_kernel<1, false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((tw_layer_kernel<1, false, false>), grid, block, 0, st, a);
+  return check_launch("tuple_layer");
+}
+
+LPG_EXPORT int lpg_tuple_fold_f64(const double* part, int64_t n_in, double* out, int64_t n_out, void* stream) {
+  LPG_REQUIRE(part && out && n_in >= 1 && n_out >= 1 && n_out <= kTwMaxPart, "tuple_fold: bad argument");
+  hipLaunchKernelGGL(tw_fold_kernel, dim3(static_cast<unsigned>(n_out)), dim3(128), 0, as_stream(stream), part,
+                     static_cast<int>(n_in), out);
+  return check_launch("tuple_fold");
+}
+
+LPG_EXPORT int lpg_tuple_apply_f32(int64_t n_node, int64_t Q, int64_t C, const float* t_node, const float* y_q,
+                                   const int32_t* cnt, const double* part, int64_t n_part, int64_t n_rows, const float* gw_a,
+                                   const float* gb_a, const float* gms_a, float eps_a, int relu_a, const float* gw_r,
+                                   const float* gb_r, const float* gms_r, float eps_r, int relu_r, const float* b_a,
+                                   const float* b_r, float* ff, float* hq, void* stream) {
+  LPG_REQUIRE(n_node >= 1 && Q >= 0 && C >= 1 && C <= 32 && n_node + Q < (int64_t(1) << 31), "tuple_apply: bad sizes");
+  LPG_REQUIRE(t_node && cnt && b_a && b_r && ff && (Q == 0 || (y_q && hq)), "tuple_apply: null pointer");
+  TwNorm nm;
+  LPG_REQUIRE(make_norm(&nm, part, n_part, n_rows, gw_a, gb_a, gms_a, eps_a, relu_a, gw_r, gb_r, gms_r, eps_r, relu_r),
+              "tuple_apply: 1 <= n_part <= %d partial blocks and n_rows >= 1 needed", kTwMaxPart);
+  hipLaunchKernelGGL(tw_apply_kernel, dim3(grid_for((n_node + Q) * 64)), dim3(kBlock), 0, as_stream(stream),
+                     static_cast<int>(n_node), static_cast<int>(Q), static_cast<int>(C), t_node, y_q, cnt, nm, b_a, b_r, ff, hq);
+  return check_launch("tuple_apply");
+}
+
+LPG_EXPORT int lpg_tuple_readout_f32(int64_t n_node, int64_t Q, int64_t C, int64_t E1, int64_t P, const int64_t* pos_edge,
+                                     const float* t_node, const float* y_q, const int32_t* cnt, const int32_t* qpos,
+                                     const double* part, int64_t n_part, const float* gw_a, const float* gb_a,
+                                     const float* gms_a, float eps_a, int relu_a, const float* gw_r, const float* gb_r,
+                                     const float* gms_r, float eps_r, int relu_r, const float* b_a, const float* b_r,
+                                     const int64_t* idx, int64_t B, const float* w, const float* b0, float* out,
+                                     int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(n_node >= 1 && Q >= 0 && C >= 1 && C <= 32 && E1 >= 0 && P >= E1 && B >= 0 && B < (int64_t(1) << 31),
+              "tuple_readout: bad sizes");
+  if (B == 0) return LPG_OK;
+  LPG_REQUIRE(t_node && cnt && qpos && b_a && b_r && idx && w && out && (E1 == 0 || pos_edge) && (Q == 0 || y_q),
+              "tuple_readout: null pointer");
+  TwNorm nm;
+  LPG_REQUIRE(make_norm(&nm, part, n_part, P, gw_a, gb_a, gms_a, eps_a, relu_a, gw_r, gb_r, gms_r, eps_r, relu_r),
+              "tuple_readout: 1 <= n_part <= %d partial blocks needed", kTwMaxPart);
+  hipLaunchKernelGGL(tw_readout_kernel, dim3(grid_for(B * 64)), dim3(kBlock), 0, as_stream(stream), static_cast<int>(n_node),
+                     static_cast<int>(Q), static_cast<int>(C), E1, P, pos_edge, t_node, y_q, cnt, qpos, nm, b_a, b_r, idx,
+                     static_cast<int>(B), w, b0, out, err_flag);
+  return check_launch("tuple_readout");
+}
+
+LPG_EXPORT int lpg_tuple_bcast_f32(int64_t P, int64_t C, int orient, const int32_t* tnode, const int32_t* cnt,
+                                   const int32_t* qpos, const float* t_node, int64_t ldt, const float* hq, int64_t ldh,
+                                   const float* bias, float* y, int64_t ldy, void* stream) {
+  LPG_REQUIRE(P >= 0 && C >= 1 && (orient == 0 || orient == 1) && ldt >= C && ldy >= C, "tuple_bcast: bad argument");
+  if (P == 0) return LPG_OK;
+  LPG_REQUIRE(tnode && cnt && qpos && t_node && y, "tuple_bcast: null pointer");
+  hipLaunchKernelGGL(tw_bcast_kernel, dim3(grid_for(P * C)), dim3(kBlock), 0, as_stream(stream), P, static_cast<int>(C), orient,
+                     tnode, cnt, qpos, t_node, ldt, hq, ldh, bias, y, ldy);
+  return check_launch("tuple_bcast");
+}

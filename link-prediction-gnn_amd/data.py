@@ -150,6 +150,7 @@ class BaseGraph:
     ``y`` and the 2-WL tuple graph ``ei2`` -- on the device."""
 
     def __init__(self, x, node_attr, edge_pos, edge_neg, num_pos, num_neg, pattern="2wl_l"):
+        """pattern: "2wl_l" (the reference's: explicit ei2), "2wl_l_implicit" (structured tuple graph, same scores)"""
         self.x, self.node_attr = x, node_attr
         self.edge_pos, self.edge_neg = edge_pos, edge_neg
         self.num_pos, self.num_neg = [int(v) for v in num_pos], [int(v) for v in num_neg]
@@ -173,6 +174,12 @@ class BaseGraph:
         if self.pattern == "2wl_l":                                                       # :94-99, a3 on the device
             self.ei2s = [twowl.get_ei2(self.num_nodes, self.edge_indexs[i].contiguous(), pred[i].contiguous())
                          for i in range(3)]
+        elif self.pattern == "2wl_l_implicit":
+            # the same tuple graph as a structured handle (twowl.TupleGraph): nothing of size E2 = sum deg^2 is built,
+            # LocalWLNet / reverse / sample_block take it where the reference passes ei2; pos1 is the handle's own list
+            self.ei2s = [twowl.TupleGraph(self.num_nodes, self.edge_indexs[i].contiguous(), pred[i].contiguous())
+                         for i in range(3)]
+            self.pos1s = [g.pos1 for g in self.ei2s]
         else:
             self.ei2s = [None] * 3
 

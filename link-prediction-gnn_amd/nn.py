@@ -91,7 +91,15 @@ class GCNConv(nn.Module):
     def forward(self, x, edge_index, edge_weight=None):
         """edge_index: [2,E] int64 tensor (PyG), or a prebuilt gcn-normalised CSRGraph."""
         _forward_only(self)
-        if isinstance(edge_index, _ops.CSRGraph):
+        if hasattr(edge_index, "orient") and hasattr(edge_index, "graph"):
+            # a twowl.TupleOrientation (reverse() of a TupleGraph): the operator form of the 2-WL aggregation -- group
+            # sums of the member rows + one broadcast, no tuple graph; the explicit edges when the layout conditions fail
+            tg = edge_index.graph
+            tp = tg.plan(operator_form=True)
+            if tp.ok and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+                return _ops.tuple_gcn_operator(tp, edge_index.orient, x, self.lin.weight, self.bias)
+            g = graph_cache.get(tg.materialize(), None, x.shape[0], True, flip=1 + edge_index.orient)
+        elif isinstance(edge_index, _ops.CSRGraph):
             g = edge_index
         else:
             g = graph_cache.get(edge_index, edge_weight, x.shape[0], True)

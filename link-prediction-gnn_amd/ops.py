@@ -683,3 +683,156 @@ def compact_cols(mat, keep):
                                         ctypes.addressof(cnt), _stream()), "compact_cols")
     c = int(cnt.value)
     return out[: rows * c].view(rows, c)
+
+
+# ------------------------------------------------------------------------------ 2-WL layers without the tuple graph
+TUPLE_MAX_C = 32          # channels the tuple-layer kernels take (lanes 0-31 / 32-63 = the two orientations)
+TUPLE_MAX_PART = 64       # partial-sum blocks a consumer folds by itself
+TUPLE_INLINE_MAX_ROW = 512    # member rows up to this length are summed inside the layer kernel (no A x launch)
+
+
+class TuplePlan:
+    """device-side structure of a twowl.TupleGraph (include/lpg_hip.h: lpg_tuple_plan_build): the member adjacency
+    `A` (unit-weight CSRGraph, rows = start node), cnt [N], qpos [P], qinfo [Q, 4], and for the operator form
+    tnode [P, 2], seg_a / seg_r [E1].  ok: pos_edge is in double()'s layout and the blocked ids come in pairs."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def tuple_plan_build(n_node, pos_edge, pred_edge, blocked=None, n_blocked_max=0, operator_form=False):
+    """blocked: uint8 mask [E1] or None; n_blocked_max: an upper bound of its set entries (sizes qinfo)."""
+    lib = _lib.load()
+    _need_gpu(pos_edge, pred_edge, blocked)
+    pos_edge, pred_edge = _c(pos_edge, torch.int64), _c(pred_edge, torch.int64)
+    dev = pos_edge.device
+    E1, Ep = pos_edge.shape[1], pred_edge.shape[1]
+    P = E1 + Ep
+    if E1 % 2 or Ep % 2 or n_node < 1:
+        return TuplePlan(ok=False, n_node=n_node, E1=E1, Ep=Ep, P=P, Q=Ep)
+    if blocked is not None:
+        keep = keep_from_blocked(None, E1, blocked)
+        members = compact_cols(pos_edge, keep)
+    else:
+        members = pos_edge
+    A = CSRGraph.from_edge_index(members, n_node, n_node)               # symmetric: rows = end = start side
+    q_cap = Ep + (min(int(n_blocked_max), E1) if blocked is not None else 0)
+    cnt = torch.empty(n_node, dtype=torch.int32, device=dev)
+    qpos = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+    qinfo = torch.empty((max(q_cap, 1), 4), dtype=torch.int32, device=dev)
+    tnode = torch.empty((max(P, 1), 2), dtype=torch.int32, device=dev) if operator_form else None
+    seg_a = torch.empty(max(E1, 1), dtype=torch.int64, device=dev) if operator_form else None
+    seg_r = torch.empty(max(E1, 1), dtype=torch.int64, device=dev) if operator_form else None
+    head = torch.empty(4, dtype=torch.int32, device=dev)
+    nbytes = _lib.check(lib.lpg_tuple_plan_bytes(P), "tuple_plan_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.lpg_tuple_plan_build(_ptr(pos_edge), E1, _ptr(pred_edge), Ep, n_node, _ptr(blocked), _ptr(A.rowptr),
+                                        _ptr(cnt), _ptr(qpos), _ptr(qinfo), q_cap, _ptr(tnode), _ptr(seg_a), _ptr(seg_r),
+                                        _ptr(head), _ptr(ws), nbytes, _ptr(err_flag(dev)), _stream()), "tuple_plan_build")
+    raise_if_flagged(dev, "tuple graph node id")                        # the build's one sync
+    h = head.tolist()
+    return TuplePlan(ok=(h[1] == 0), n_node=int(n_node), E1=E1, Ep=Ep, P=P, Q=int(h[0]), A=A, cnt=cnt, qpos=qpos,
+                     qinfo=qinfo, tnode=tnode, seg_a=seg_a[:E1] if operator_form else None,
+                     seg_r=seg_r[:E1] if operator_form else None, pos_edge=pos_edge, pred_edge=pred_edge, q_cap=q_cap)
+
+
+def _norm_args(norm, relu):
+    w, b, ms = _c(norm.weight, torch.float32), _c(norm.bias, torch.float32), _c(norm.mean_scale, torch.float32)
+    _lib.keepalive(w, b, ms)
+    return [_ptr(w), _ptr(b), _ptr(ms), float(norm.eps), int(relu)]
+
+
+def tuple_layer(plan, mode, x, ax, w_a, w_r, b_a, b_r, hq_prev=None, want_t=True):
+    """one 2-WL layer over a TuplePlan (lpg_tuple_layer_f32).  mode 1: x = the 1-WL output [N, C] (a tensor or a
+    `Deferred`), ax = A x or None (summed inside); mode 2: x = (F_a | F_r) [N, 2C], ax = A x, hq_prev [Q, C].
+    -> (t_node [N, 2C] or None, y_q [Q, 2C], part [n_blocks, 2, 64])"""
+    lib = _lib.load()
+    dfr = x if isinstance(x, Deferred) else None
+    xt = _c(dfr.y if dfr is not None else x, torch.float32)
+    ax = _c(ax, torch.float32)
+    w_a, w_r, b_a, b_r = (_c(v, torch.float32) for v in (w_a, w_r, b_a, b_r))
+    _need_gpu(xt, ax, w_a, w_r, b_a, b_r, hq_prev)
+    C = w_a.shape[0]
+    N, Q = plan.n_node, plan.Q
+    if w_a.shape != (C, C) or w_r.shape != (C, C) or C > TUPLE_MAX_C or xt.shape != (N, C if mode == 1 else 2 * C):
+        raise ValueError("tuple_layer: shapes do not match (square [C, C] weights, C <= 32, x [N, C] / [N, 2C])")
+    if ax is not None and ax.shape != xt.shape:
+        raise ValueError("tuple_layer: A x must have x's shape")
+    dev = xt.device
+    nb = int(_lib.check(lib.lpg_tuple_layer_blocks(N, Q), "tuple_layer_blocks"))
+    t_node = torch.empty((N, 2 * C), dtype=torch.float32, device=dev) if want_t else None
+    y_q = torch.empty((max(Q, 1), 2 * C), dtype=torch.float32, device=dev)
+    part = torch.empty((nb, 2, 64), dtype=torch.float64, device=dev)
+    if dfr is not None and dfr.part is not None:
+        nm = dfr.norm
+        gw, gb, gms = _c(nm.weight, torch.float32), _c(nm.bias, torch.float32), _c(nm.mean_scale, torch.float32)
+        din = [_ptr(dfr.part), _ptr(gw), _ptr(gb), _ptr(gms), dfr.part.shape[0], int(dfr.relu), N, float(nm.eps)]
+        _lib.keepalive(dfr.part, gw, gb, gms)
+    else:
+        din = [0, 0, 0, 0, 1, 0, 1, 1e-5]
+    hq_prev = _c(hq_prev, torch.float32)
+    _lib.keepalive(xt, ax, plan.A.rowptr, plan.A.col, hq_prev, plan.cnt, plan.qinfo, w_a, w_r, b_a, b_r, t_node, y_q, part)
+    _lib.call("lpg_tuple_layer_f32", int(mode), N, Q, C, _ptr(xt), xt.stride(0), _ptr(ax), 0 if ax is None else ax.stride(0),
+              _ptr(plan.A.rowptr), _ptr(plan.A.col), _ptr(hq_prev), _ptr(plan.cnt), _ptr(plan.qinfo), _ptr(w_a), _ptr(w_r),
+              _ptr(b_a), _ptr(b_r), _ptr(t_node), _ptr(y_q), _ptr(part), nb, *din, _stream())
+    if nb > TUPLE_MAX_PART:                    # big graphs: one more small launch folds the partial sums
+        folded = torch.empty((16, 2, 64), dtype=torch.float64, device=dev)
+        _lib.check(lib.lpg_tuple_fold_f64(_ptr(part), nb, _ptr(folded), 16, _stream()), "tuple_fold")
+        part = folded
+    return t_node, y_q, part
+
+
+def tuple_apply(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, b_r):
+    """GraphNorm (+ ReLU) of a 2-WL layer's two outputs, for the next layer: ff [N, 2C] = (F_a | F_r), hq [Q, C]"""
+    lib = _lib.load()
+    C = t_node.shape[1] // 2
+    b_a, b_r = _c(b_a, torch.float32), _c(b_r, torch.float32)
+    ff = torch.empty_like(t_node)
+    hq = torch.empty((max(plan.Q, 1), C), dtype=torch.float32, device=t_node.device)
+    _lib.check(lib.lpg_tuple_apply_f32(plan.n_node, plan.Q, C, _ptr(t_node), _ptr(y_q), _ptr(plan.cnt), _ptr(part),
+                                       part.shape[0], plan.P, *_norm_args(norm_a, relu_a), *_norm_args(norm_r, relu_r),
+                                       _ptr(b_a), _ptr(b_r), _ptr(ff), _ptr(hq), _stream()), "tuple_apply")
+    return ff, hq
+
+
+def tuple_readout(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, b_r, idx, w, b0):
+    """TwoWL/model/model.py:78-83 over the last 2-WL layer (GraphNorm + ReLU applied on load) -> [B, 1] logits"""
+    C = t_node.shape[1] // 2
+    idx = _c(idx.reshape(-1), torch.int64)
+    _need_gpu(t_node, y_q, idx, w, b0)
+    B = idx.numel() // 2
+    out = torch.empty((B, 1), dtype=torch.float32, device=t_node.device)
+    b_a, b_r, w, b0 = _c(b_a, torch.float32), _c(b_r, torch.float32), _c(w.reshape(-1), torch.float32), _c(b0, torch.float32)
+    na, nr = _norm_args(norm_a, relu_a), _norm_args(norm_r, relu_r)
+    _lib.keepalive(plan.pos_edge, t_node, y_q, plan.cnt, plan.qpos, part, b_a, b_r, idx, w, b0, out)
+    _lib.call("lpg_tuple_readout_f32", plan.n_node, plan.Q, C, plan.E1, plan.P, _ptr(plan.pos_edge), _ptr(t_node), _ptr(y_q),
+              _ptr(plan.cnt), _ptr(plan.qpos), _ptr(part), part.shape[0], *na, *nr, _ptr(b_a), _ptr(b_r), _ptr(idx), B,
+              _ptr(w), _ptr(b0), _ptr(out), _ptr(err_flag(t_node.device)), _stream())
+    return out
+
+
+def tuple_gcn_operator(plan, orient, x, weight, bias):
+    """GCNConv(x, edge2 | edge2_r) for an ARBITRARY [P, C_in] input without the tuple graph (the operator form:
+    TwoWL/model/model.py:77 called module by module): group sums of the member rows (the atomic-free scatter_add),
+    the layer's linear on N + Q rows instead of P, and one broadcast launch."""
+    lib = _lib.load()
+    x = _c(x, torch.float32)
+    _need_gpu(x, weight, bias)
+    P, N, E1 = plan.P, plan.n_node, plan.E1
+    if x.shape[0] != P:
+        raise ValueError(f"tuple_gcn_operator: x must have one row per tuple ({P}), got {x.shape[0]}")
+    sums = torch.zeros((N + 1, x.shape[1]), dtype=torch.float32, device=x.device)      # row N collects the blocked tuples
+    if E1:
+        scatter_add_rows(x[:E1], plan.seg_a if orient == 0 else plan.seg_r, sums, fresh=False)
+    t_node = linear(sums[:N], weight)
+    C = t_node.shape[1]
+    hq = None
+    if plan.Q:
+        qrows = plan.qinfo[: plan.Q, 3].to(torch.int64)
+        hq = linear(embedding(x, qrows), weight)
+    y = torch.empty((P, C), dtype=torch.float32, device=x.device)
+    bias = _c(bias, torch.float32)
+    _lib.check(lib.lpg_tuple_bcast_f32(P, C, int(orient), _ptr(plan.tnode), _ptr(plan.cnt), _ptr(plan.qpos), _ptr(t_node),
+                                       t_node.stride(0), _ptr(hq), 0 if hq is None else hq.stride(0), _ptr(bias), _ptr(y),
+                                       y.stride(0), _stream()), "tuple_bcast")
+    return y

@@ -27,7 +27,10 @@ def degree(ei, num_node: int):
 
 
 def reverse(edge_index):
-    """TwoWL/utils.py:71-78 -- (edge, edge_r) with the partner-direction tuple id flipped."""
+    """TwoWL/utils.py:71-78 -- (edge, edge_r) with the partner-direction tuple id flipped.  A `TupleGraph` gives its
+    two orientation handles instead (GCNConv takes them as edge_index: the operator form, no tuple graph built)."""
+    if isinstance(edge_index, TupleGraph):
+        return edge_index.reverse()
     return _ops.flip_index(edge_index)
 
 
@@ -48,6 +51,72 @@ def double(x, for_index=False):
     return out
 
 
+class TupleOrientation:
+    """one of the two orientations reverse() makes of a TupleGraph; nn.GCNConv accepts it where the reference passes
+    edge2 / edge2_r (TwoWL/model/model.py:77)."""
+
+    def __init__(self, graph, orient):
+        self.graph, self.orient = graph, int(orient)
+
+
+class TupleGraph:
+    """get_ei2(n_node, pos_edge, pred_edge) (TwoWL/utils.py:36-45) in STRUCTURED form: the tuple graph is the union of
+    one complete bipartite block per node, so it is fully described by the two edge lists (plus the blocked tuple ids
+    of blockei2, :48-50) and is never materialised -- E2 = sum deg^2 edges on a graph where the lists have sum deg.
+    LocalWLNet.forward(..., ei2=TupleGraph) computes the same scores from per-node sums (csrc/tuple_wl.hip);
+    reverse() / sample_block() / blockei2() accept it; materialize() builds the explicit [2, E2] tensor (tests, or
+    when pos_edge is not in double()'s layout)."""
+
+    def __init__(self, n_node, pos_edge, pred_edge, blocked_idx=None):
+        self.n_node = int(n_node)
+        self.pos_edge, self.pred_edge = pos_edge, pred_edge
+        self.blocked_idx = blocked_idx
+        self.E1, self.Ep = pos_edge.shape[1], pred_edge.shape[1]
+        self.P = self.E1 + self.Ep
+        self._plan = self._ei2 = self._pos1 = None
+
+    @property
+    def pos1(self):
+        """the [P, 2] tuple list the reference builds next to ei2 (TwoWL/operators/datasets.py:79-82)"""
+        if self._pos1 is None:
+            self._pos1 = torch.cat((self.pos_edge.t(), self.pred_edge.t()), dim=0).contiguous()
+        return self._pos1
+
+    def plan(self, operator_form=False):
+        if self._plan is None or (operator_form and self._plan.ok and self._plan.tnode is None):
+            blocked = None
+            nb = 0
+            if self.blocked_idx is not None and self.blocked_idx.numel():
+                blocked = _ops.mark(self.blocked_idx, self.E1)
+                _ops.maybe_check(self.pos_edge.device, "blocked tuple id")
+                nb = self.blocked_idx.numel()
+            self._plan = _ops.tuple_plan_build(self.n_node, self.pos_edge, self.pred_edge, blocked, nb, operator_form)
+        return self._plan
+
+    def block(self, blocked_idx):
+        """blockei2(ei2, blocked_idx) (TwoWL/utils.py:48-50) on the structured form"""
+        if self.blocked_idx is not None and self.blocked_idx.numel():
+            blocked_idx = torch.cat((self.blocked_idx.reshape(-1), blocked_idx.reshape(-1)))
+        return TupleGraph(self.n_node, self.pos_edge, self.pred_edge, blocked_idx)
+
+    def reverse(self):
+        return TupleOrientation(self, 0), TupleOrientation(self, 1)
+
+    def materialize(self):
+        if self._ei2 is None:
+            ei2 = get_ei2(self.n_node, self.pos_edge, self.pred_edge)
+            if self.blocked_idx is not None and self.blocked_idx.numel():
+                ei2 = blockei2(ei2, self.blocked_idx, self.P)
+            self._ei2 = ei2
+        return self._ei2
+
+
+def tuple_graph(n_node: int, pos_edge, pred_edge):
+    """get_ei2's arguments -> the structured tuple graph (nothing of size E2 is built)"""
+    return TupleGraph(n_node, pos_edge, pred_edge)
+
+
+_IMPLICIT_MODE = "node"        # "node": per-node sums all the way (csrc/tuple_wl.hip); "operator": GCNConv per orientation
 _side_streams = {}
 _PARALLEL_BRANCHES = os.environ.get("LPG_TWOWL_PARALLEL", "1") != "0"
 _SMALL_PATH = os.environ.get("LPG_TWOWL_SMALL", "1") != "0"      # A/B hook: 0 keeps the kernel-per-op path
@@ -96,6 +165,8 @@ class _SmallPlan:
 
 
 def _tkey(t):
+    if isinstance(t, TupleGraph):
+        return (id(t), _tkey(t.pos_edge), _tkey(t.pred_edge), None if t.blocked_idx is None else _tkey(t.blocked_idx))
     return (t.data_ptr(), t._version, t.shape[0])
 
 
@@ -151,31 +222,107 @@ class LocalWLNet(nn.Module):
                 plan.block[plan.out_word] = out.data_ptr()
                 _lib.check(_lib.load().lpg_twowl_forward_small(plan.ptr, plan.n_words, _ops._stream()), "twowl_forward_small")
                 return out
-        # K8: reverse(ei2) is never materialised -- the flips are folded into the two CSR builds
-        # (edge2 = (flip(e0), e1), edge2_r = (e0, flip(e1))), memoised on ei2's identity.
         P = pos.shape[0]
-        edge2 = graph_cache.get(ei2, None, P, True, flip=1)
-        edge2_r = graph_cache.get(ei2, None, P, True, flip=2)
-        if self._small_graph_ok(x, edge1, P):
-            if idx is None or ei2 is None or self.use_node_feat or torch.cuda.is_current_stream_capturing():
-                return self._forward_small(x, edge1, pos, idx, edge2, edge2_r)      # (the block format has no linear / LayerNorm launch)
+        tg = None
+        if isinstance(ei2, TupleGraph):
+            # the structured tuple graph: per-node sums instead of E2 = sum deg^2 edges (csrc/tuple_wl.hip) whenever the
+            # layout conditions hold; otherwise the explicit tensor, as the reference builds it
+            tg = ei2 if self._implicit_ok(ei2, pos, idx) else None
+            if tg is None:
+                ei2 = ei2.materialize()
+        node_mode = tg is not None and _IMPLICIT_MODE == "node"
+        if tg is None:
+            # K8: reverse(ei2) is never materialised -- the flips are folded into the two CSR builds
+            # (edge2 = (flip(e0), e1), edge2_r = (e0, flip(e1))), memoised on ei2's identity.
+            edge2 = graph_cache.get(ei2, None, P, True, flip=1)
+            edge2_r = graph_cache.get(ei2, None, P, True, flip=2)
+        elif node_mode:
+            edge2 = edge2_r = None
+        else:
+            edge2, edge2_r = tg.reverse()
+        if self._small_graph_ok(x, edge1, P, node_mode) and (tg is None or node_mode):
+            if (idx is None or ei2 is None or self.use_node_feat or torch.cuda.is_current_stream_capturing()
+                    or (node_mode and not self._tuple_recordable(tg))):
+                return self._forward_small(x, edge1, pos, idx, edge2, edge2_r, tg)      # (the block format has no linear / LayerNorm / SpMM launch)
             # first forward over these inputs: run the launches one by one, recording them (and checking the indices:
             # the recorded block is only replayed for the same tensors at the same versions, so once is enough)
             self._plan_params = [p for p in self.parameters()]
             key = (_tkey(x), _tkey(edge1) if torch.is_tensor(edge1) else id(edge1), _tkey(pos), _tkey(idx), _tkey(ei2),
                    tuple([p._version for p in self._plan_params]))
+            if node_mode:
+                tg.plan()                          # built (and synchronised) outside the recording
             with _lib.recording() as rec:
-                out = self._forward_small(x, edge1, pos, idx, edge2, edge2_r)
+                out = self._forward_small(x, edge1, pos, idx, edge2, edge2_r, tg)
             self._plan = _SmallPlan(key, rec["words"], rec["keep"] + [x, edge1, pos, idx, ei2, edge2, edge2_r],
                                     tuple(out.shape), out.device)
             return out
         x = self._input_features(x)
         for conv1 in self.conv1s:
             x = conv1(x, edge1)                                        # K5 + K3/K4 + K6
+        if node_mode:
+            return self._two_wl_node(x, tg, idx)                       # a6 + a7 + a8 on per-node sums
         x = _ops.pair_gather_mul(x, pos)                               # K7
         for i in range(len(self.conv2s)):
             x = self._both_orientations(self.conv2s[i], self.conv2s_r[i], x, edge2, edge2_r)   # a7
         out = _ops.pair_readout(x, idx, self.pred.weight, self.pred.bias)   # K9
+        _ops.maybe_check(out.device, "LocalWLNet index")
+        return out
+
+    def _implicit_ok(self, tg, pos, idx):
+        """the per-node form applies: idx given, the 2-WL layers are the reference's relu_conv blocks of <= 32 channels,
+        pos_edge is in double()'s layout with blocked ids in pairs (TuplePlan.ok), and `pos` is the tuple list of the
+        same two edge lists (checked once per tensor)."""
+        convs = list(self.conv2s) + list(self.conv2s_r)
+        if (idx is None or not tg.pos_edge.is_cuda or len(self.conv2s) != len(self.conv2s_r) or not convs
+                or pos.shape != (tg.P, 2)
+                or not all(_is_relu_conv(s) and s.modlist[0].in_channels == s.modlist[0].out_channels <= _ops.TUPLE_MAX_C
+                           for s in convs)):
+            return False
+        if not tg.plan(operator_form=_IMPLICIT_MODE != "node").ok:
+            return False
+        if pos is tg._pos1:
+            return True
+        seen = tg.__dict__.setdefault("_pos_seen", {})
+        k = _tkey(pos)
+        if k not in seen:
+            seen.clear()
+            seen[k] = bool(torch.equal(pos, tg.pos1))
+        return seen[k]
+
+    def _tuple_recordable(self, tg):
+        """the per-node 2-WL stage is two launches (layer with the member rows summed inside + readout) that the
+        recorded argument block can hold"""
+        tp = tg.plan()
+        return (len(self.conv2s) == 1 and 0 <= tp.A.max_row <= _ops.TUPLE_INLINE_MAX_ROW
+                and _lib.load().lpg_tuple_layer_blocks(tp.n_node, tp.Q) <= _ops.TUPLE_MAX_PART)
+
+    def _two_wl_node(self, x1, tg, idx):
+        """model.py:75-83 without the tuple graph: x1 = the 1-WL output [N, C] (tensor or `Deferred`).  Per 2-WL layer:
+        (A x) over the member adjacency -- inside the layer kernel when its rows are short --, one launch for both
+        orientations' node tables and non-member rows, GraphNorm folded into whichever kernel reads the result."""
+        tp = tg.plan()
+        t = yq = part = prev = None
+        for l, (seq_a, seq_r) in enumerate(zip(self.conv2s, self.conv2s_r)):
+            ca, cr = seq_a.modlist[0], seq_r.modlist[0]
+            zeros = None
+            if ca.bias is None or cr.bias is None:
+                zeros = torch.zeros(ca.out_channels, dtype=torch.float32, device=tp.cnt.device)
+            ba, br = (ca.bias if ca.bias is not None else zeros), (cr.bias if cr.bias is not None else zeros)
+            cur = (seq_a.modlist[1], isinstance(seq_a.modlist[3], nn.ReLU), seq_r.modlist[1], isinstance(seq_r.modlist[3], nn.ReLU), ba, br)
+            if l == 0:
+                if 0 <= tp.A.max_row <= _ops.TUPLE_INLINE_MAX_ROW:
+                    ax = None
+                else:
+                    if isinstance(x1, _ops.Deferred):
+                        x1 = x1.norm(x1.y, relu=x1.relu) if x1.part is not None else x1.y
+                    ax = tp.A.spmm(x1, use_val=False)
+                t, yq, part = _ops.tuple_layer(tp, 1, x1, ax, ca.lin.weight, cr.lin.weight, ba, br)
+            else:
+                ff, hq = _ops.tuple_apply(tp, t, yq, part, *prev)
+                aff = tp.A.spmm(ff, use_val=False)
+                t, yq, part = _ops.tuple_layer(tp, 2, ff, aff, ca.lin.weight, cr.lin.weight, ba, br, hq_prev=hq)
+            prev = cur
+        out = _ops.tuple_readout(tp, t, yq, part, *prev, idx, self.pred.weight, self.pred.bias)
         _ops.maybe_check(out.device, "LocalWLNet index")
         return out
 
@@ -187,19 +334,19 @@ class LocalWLNet(nn.Module):
             return _ops.layer_norm_rows(_ops.linear(self.node_feat, lin.weight, lin.bias), ln.eps)
         return self.emb[1](_ops.embedding(self.emb[0].weight, x))
 
-    def _small_graph_ok(self, x, edge1, P):
+    def _small_graph_ok(self, x, edge1, P, node_mode=False):
         if not (_SMALL_PATH and (self.node_feat if self.use_node_feat else x).is_cuda and not isinstance(edge1, _ops.CSRGraph)):
             return False
         cap = _ops.small_max_rows()
         convs = list(self.conv1s) + list(self.conv2s) + list(self.conv2s_r)
         n = self.node_feat.shape[0] if self.use_node_feat else x.shape[0]
         c1 = self.conv1s[0].modlist[0].in_channels
-        return (0 < n <= cap and 0 < P <= cap and c1 % 4 == 0
+        return (0 < n <= cap and (node_mode or 0 < P <= cap) and c1 % 4 == 0
                 and len(self.conv2s) == len(self.conv2s_r) >= 1
                 and all(_is_relu_conv(s) and s.modlist[0].in_channels <= 256 for s in convs)
                 and len({s.modlist[1].eps for s in convs}) == 1)
 
-    def _forward_small(self, x, edge1, pos, idx, edge2, edge2_r):
+    def _forward_small(self, x, edge1, pos, idx, edge2, edge2_r, tg=None):
         """the same forward for graphs of <= 8192 nodes / tuples (the reference's fb-pages-food: 620 / 4252), where
         the kernel-per-op path is launch-bound: 2 launches per GCN block (linear -> transposed features; aggregation
         + bias per (feature column, row block) out of LDS), GraphNorm + ReLU deferred into whichever kernel reads
@@ -226,6 +373,8 @@ class LocalWLNet(nn.Module):
         for seq in convs:
             hT = _ops.small_linear_t(h, seq.modlist[0].lin.weight)
             h, = _ops.small_gcn(N, [_side(hT, g1, seq)])
+        if tg is not None:
+            return self._two_wl_node(h, tg, idx)        # conv1's GraphNorm + ReLU is applied by the layer kernel on load
         a = r = None
         for i, (seq_a, seq_r) in enumerate(zip(self.conv2s, self.conv2s_r)):
             wa, wr = seq_a.modlist[0].lin.weight, seq_r.modlist[0].lin.weight
@@ -335,7 +484,9 @@ def idx2mask(num: int, idx):
 
 
 def blockei2(ei2, blocked_idx, n_tuples=None):
-    """TwoWL/utils.py:48-50 -- drop tuple-graph edges whose SOURCE tuple is blocked."""
+    """TwoWL/utils.py:48-50 -- drop tuple-graph edges whose SOURCE tuple is blocked (a TupleGraph records the ids)."""
+    if isinstance(ei2, TupleGraph):
+        return ei2.block(blocked_idx)
     n_tuples = int(n_tuples) if n_tuples is not None else int(max(ei2.max().item(), blocked_idx.max().item())) + 1
     blocked = _ops.mark(blocked_idx, n_tuples)
     keep = _ops.keep_from_blocked(ei2[0], ei2.shape[1], blocked)

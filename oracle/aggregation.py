@@ -344,3 +344,98 @@ def seal_head_mag(z, key, hw):
     az = {k: np.abs(np.asarray(v, dtype=np.float64)) for k, v in hw.items()}
     pre_y, _ = seal_head(np.abs(np.asarray(z, dtype=np.float64)), key, az)
     return pre_y
+
+
+# ----------------------------------------------------------------------------- TwoWL forward without the tuple graph
+def tuple_structure(n_node, pos_edge, pred_edge, blocked=None):
+    """what the tuple graph of TwoWL/utils.py:36-45 (get_ei2), after blockei2 (:48-50) and reverse (:71-78), looks like
+    when pos_edge is in double()'s layout (:81-90: columns 2k / 2k + 1 are the two directions of one edge) and the
+    blocked tuple ids come in such pairs too (TwoWL/model/train.py:26: double(idx1, for_index=True)):
+
+      orientation a (edge2   = (flip(a), b)):  the in-neighbours of tuple b are the MEMBER tuples (graph tuples that are
+                                               not blocked) that START at node_a(b) = start(b);
+      orientation r (edge2_r = (a, flip(b))):  the in-neighbours of b are the members that END at node_r(b) = start(b^1)
+                                               (= end(b) when the candidates are doubled as well);
+      add_remaining_self_loops gives b one more in-edge (itself) exactly when b is not a member;
+      every member in a group has the same degree cnt(node) = the group's size.
+
+    Returns dict(start, end, node_a, node_r, member, cnt, ok); ok = the layout conditions hold."""
+    pos_edge = np.asarray(pos_edge, dtype=np.int64)
+    edge = np.concatenate([pos_edge, np.asarray(pred_edge, dtype=np.int64)], axis=1)
+    E1, P = pos_edge.shape[1], edge.shape[1]
+    member = np.zeros(P, dtype=bool)
+    member[:E1] = True
+    if blocked is not None:
+        member[np.asarray(blocked, dtype=np.int64)] = False
+    ok = E1 % 2 == 0 and P % 2 == 0
+    if ok:
+        ok = bool(np.array_equal(pos_edge[0, 0::2], pos_edge[1, 1::2]) and np.array_equal(pos_edge[1, 0::2], pos_edge[0, 1::2])
+                  and np.array_equal(member[0::2], member[1::2]))
+    start, end = edge[0], edge[1]
+    partner = np.arange(P) ^ 1 if P % 2 == 0 else np.arange(P)
+    cnt = np.bincount(start[member], minlength=n_node).astype(np.int64)
+    return {"start": start, "end": end, "node_a": start, "node_r": start[partner], "member": member, "cnt": cnt, "ok": ok}
+
+
+def localwl_forward_collapsed(params, x_deg, edge1, pos_edge, pred_edge, idx, n_node, blocked=None):
+    """the same function as localwl_forward(params, x_deg, edge1, cat(pos_edge, pred_edge).T, idx,
+    blockei2(get_ei2(n_node, pos_edge, pred_edge), blocked)) -- TwoWL/model/model.py:68-84 -- computed WITHOUT the
+    tuple graph: every per-node block of get_ei2 is a complete bipartite graph whose sources share one degree, so a
+    2-WL layer is a per-node sum over the member tuples plus a broadcast, and because member tuples' features are
+    themselves node-level (x[u] * x[v] at layer 0; F_a[start] + F_r[end] after a layer) those sums are products with
+    the member adjacency A.  O((N + Q) C^2 + E1 C) instead of O(E2 C), Q = non-member tuples.  fp64."""
+    p = params
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    s = tuple_structure(n_node, pos_edge, pred_edge, blocked)
+    if not s["ok"]:
+        raise ValueError("pos_edge / blocked are not in double() layout")
+    start, end, member, cnt = s["start"], s["end"], s["member"], s["cnt"].astype(np.float64)
+    P = start.shape[0]
+    x = input_features(p, x_deg)
+    for l in range(p["depth1"]):
+        x = gcn_conv(x, edge1, p[f"conv1s.{l}.lin.weight"], p[f"conv1s.{l}.bias"])
+        x = graph_norm(x, p[f"conv1s.{l}.norm.weight"], p[f"conv1s.{l}.norm.bias"], p[f"conv1s.{l}.norm.mean_scale"])
+        if p[f"conv1s.{l}.act"]:
+            x = np.maximum(x, 0.0)
+    ms_, me_ = start[member], end[member]
+
+    class _Adj:                                                # the member adjacency (symmetric by the layout conditions)
+        def __matmul__(self, v):
+            out = np.zeros((n_node, v.shape[1]))
+            np.add.at(out, ms_, v[me_])
+            return out
+    A = _Adj()
+    q = np.nonzero(~member)[0]
+    na, nr = s["node_a"][q], s["node_r"][q]
+    hq = x[start[q]] * x[end[q]]
+    Fa = Fr = None
+    safe = np.maximum(cnt, 1.0)
+    for l in range(p["depth2"]):
+        if l == 0:
+            sx_a = sx_r = x * (A @ x)
+        else:
+            sx_a = cnt[:, None] * Fa + A @ Fr
+            sx_r = A @ Fa + cnt[:, None] * Fr
+        outs = []
+        for name, sx, nq in (("conv2s", sx_a, na), ("conv2s_r", sx_r, nr)):
+            wt, b = f64(p[f"{name}.{l}.lin.weight"]).T, f64(p[f"{name}.{l}.bias"])
+            T = sx @ wt
+            M = T / safe[:, None] + b[None, :]                                  # every member row of node i
+            c = cnt[nq]
+            yq = T[nq] * np.where(c > 0, 1.0 / np.sqrt(np.maximum(c, 1.0) * (c + 1.0)), 0.0)[:, None] \
+                + (hq @ wt) / (c + 1.0)[:, None] + b[None, :]
+            w, gb, ms = (f64(p[f"{name}.{l}.norm.{k}"]) for k in ("weight", "bias", "mean_scale"))
+            s1 = (cnt[:, None] * M).sum(0) + yq.sum(0)
+            mean = s1 / P
+            o_n, o_q = M - mean * ms, yq - mean * ms
+            var = ((cnt[:, None] * o_n * o_n).sum(0) + (o_q * o_q).sum(0)) / P
+            sc = w / np.sqrt(var + 1e-5)
+            outs.append((np.maximum(o_n * sc + gb, 0.0), np.maximum(o_q * sc + gb, 0.0)))
+        Fa, Fr = outs[0][0], outs[1][0]
+        hq = outs[0][1] + outs[1][1]
+    idx = np.asarray(idx, dtype=np.int64)
+    qpos = np.full(P, -1, dtype=np.int64)
+    qpos[q] = np.arange(q.size)
+    rows = np.where(member[idx][:, None], Fa[start[idx]] + Fr[end[idx]], hq[np.maximum(qpos[idx], 0)])
+    z = rows[0::2] * rows[1::2]
+    return z @ f64(p["pred.weight"]).T + f64(p["pred.bias"])[None, :]

@@ -2199,3 +2199,208 @@ def test_config4_rmat_10m_200m_d256(dev, dtype):
     w = (torch.randn((d, d), generator=gen, device=dev) / 16).to(dtype)
     _spmm_properties(dev, ei, N, d, dtype, seed=404, w_dense=w)
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ the 2-WL stage WITHOUT the tuple graph (csrc/tuple_wl.hip)
+def _tuple_case(rng, trial, n_lo=3, n_hi=40, e_hi=80, ep_hi=30):
+    from oracle import twowl_int
+    n = int(rng.integers(n_lo, n_hi))
+    e, ep = int(rng.integers(1, e_hi)), int(rng.integers(2, ep_hi))
+    pos_edge = twowl_int.double(rng.integers(0, n, size=(2, e)))                 # self loops and duplicate edges included
+    cand = rng.integers(0, n + 3, size=(2, ep))                                  # nodes n..n+2 only appear in candidates
+    pred_edge = twowl_int.double(cand) if trial % 3 else np.ascontiguousarray(cand[:, : (ep // 2) * 2])
+    blocked = twowl_int.double(rng.choice(e, size=max(1, e // 4), replace=False), for_index=True) if trial % 2 else None
+    return n + 3, pos_edge, pred_edge, blocked
+
+
+def test_tuple_plan_matches_oracle_structure(dev):
+    """lpg_tuple_plan_build against oracle.aggregation.tuple_structure: member counts, non-member numbering in tuple
+    order, (start, end, node_r, id) per non-member, the operator form's node / scatter indices, and the layout verdict."""
+    from lpgnn_amd import ops
+    from oracle import aggregation as agg, twowl_int
+    rng = np.random.default_rng(41)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for trial in range(12):
+        N, pe, pr, blocked = _tuple_case(rng, trial)
+        s = agg.tuple_structure(N, pe, pr, blocked)
+        mask = None
+        if blocked is not None:
+            mask = np.zeros(pe.shape[1], np.uint8)
+            mask[blocked] = 1
+        tp = ops.tuple_plan_build(N, t(pe), t(pr), t(mask), 0 if blocked is None else blocked.size, operator_form=True)
+        assert tp.ok and s["ok"]
+        q = np.nonzero(~s["member"])[0]
+        assert tp.Q == q.size and np.array_equal(_np(tp.cnt), s["cnt"])
+        qpos = np.full(s["member"].size, -1)
+        qpos[q] = np.arange(q.size)
+        assert np.array_equal(_np(tp.qpos)[: qpos.size], qpos)
+        want = np.stack([s["start"][q], s["end"][q], s["node_r"][q], q], axis=1)
+        assert np.array_equal(_np(tp.qinfo)[: q.size], want)
+        assert np.array_equal(_np(tp.tnode)[: qpos.size], np.stack([s["node_a"], s["node_r"]], axis=1))
+        E1 = pe.shape[1]
+        assert np.array_equal(_np(tp.seg_a), np.where(s["member"][:E1], s["start"][:E1], N))
+        assert np.array_equal(_np(tp.seg_r), np.where(s["member"][:E1], s["end"][:E1], N))
+    # layouts the per-node form does not cover are reported, not computed
+    und = rng.integers(0, 9, size=(2, 10))
+    pos, pred = twowl_int.double(und), twowl_int.double(rng.integers(0, 9, size=(2, 4)))
+    assert not ops.tuple_plan_build(9, t(pos[:, rng.permutation(20)]), t(pred)).ok
+    one = np.zeros(20, np.uint8)
+    one[2] = 1
+    assert not ops.tuple_plan_build(9, t(pos), t(pred), t(one), 1).ok
+    assert not ops.tuple_plan_build(9, t(pos[:, :-1]), t(pred)).ok
+    with pytest.raises(IndexError):
+        ops.tuple_plan_build(5, t(pos), t(pred))                      # node ids up to 8
+
+
+@pytest.mark.parametrize("c1,c2,d1,d2", [(256, 32, 1, 1), (24, 16, 2, 2), (64, 24, 3, 1), (32, 32, 1, 3)])
+def test_localwl_implicit_fb_pages_food(dev, tw, c1, c2, d1, d2, monkeypatch):
+    """LocalWLNet.forward(..., ei2=TupleGraph) on the reference's fb-pages-food test split: the per-node form (small-graph
+    launches; kernel-per-op 1-WL stage; operator form through GCNConv(x, orientation)) against the fp64 oracle over the
+    EXPLICIT tuple graph the reference builds (tests/golden/twowl_int.npz): every logit within 1e-5 of the logit scale,
+    bitwise reproducible, and the recorded one-call replay returns the same bits."""
+    from lpgnn_amd import twowl
+    from oracle import aggregation as agg
+    mod, x_deg, ei, pred, ei2, pos1 = _localwl_case(tw, c1, c2, d1, d2, dev)
+    y_len = pred.shape[1]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    idx = ei.shape[1] + np.arange(y_len)
+    want = agg.localwl_forward(mod.export_params(), x_deg, ei, pos1, idx, ei2)
+    scale = np.abs(want).max()
+    tg = twowl.tuple_graph(620, t(ei), t(pred))
+    assert tg.plan().ok and tg.plan().Q == y_len
+    xd, eid, posd = t(x_deg), t(ei), t(pos1)
+    for mode, small in (("node", True), ("node", False), ("operator", False)):
+        monkeypatch.setattr(twowl, "_IMPLICIT_MODE", mode)
+        monkeypatch.setattr(twowl, "_SMALL_PATH", small)
+        mod.invalidate_plans()
+        logits = twowl.test_forward(mod, xd, eid, posd, y_len, tg)
+        again = twowl.test_forward(mod, xd, eid, posd, y_len, tg)                 # the replayed block on the small path
+        third = twowl.test_forward(mod, xd, eid, tg.pos1, y_len, tg)              # the handle's own tuple list
+        if mode == "node":
+            assert torch.equal(logits, again) and torch.equal(logits, third)
+        if mode == "node" and small and d2 == 1:
+            assert mod._plan is not None                                         # two launches recorded for the 2-WL stage
+        got = _np(logits).astype(np.float64)
+        assert got.shape == want.shape and np.abs(got - want).max() <= TOL * scale, (mode, small, np.abs(got - want).max() / scale)
+        print(f"implicit {mode} small={small} {c1}/{c2}/{d1}/{d2}: max |logit error| {np.abs(got - want).max() / scale:.1e} of the scale")
+    # a `pos` that is NOT the handle's tuple list must not take the per-node form (it falls back to the explicit graph)
+    monkeypatch.setattr(twowl, "_IMPLICIT_MODE", "node")
+    monkeypatch.setattr(twowl, "_SMALL_PATH", True)
+    mod.invalidate_plans()
+    other = pos1.copy()
+    other[5] = other[7]
+    got = _np(twowl.test_forward(mod, xd, eid, t(other), y_len, tg)).astype(np.float64)
+    want_o = agg.localwl_forward(mod.export_params(), x_deg, ei, other, idx, ei2)
+    assert np.abs(got - want_o).max() <= TOL * np.abs(want_o).max()
+
+
+def test_localwl_implicit_random_graphs(dev, monkeypatch):
+    """implicit (per-node and operator form) == explicit device path == fp64 oracle on random graphs with self-loop
+    tuples, duplicate edges, nodes that only appear in candidates, blocked tuple pairs (sample_block's ei2_new),
+    un-doubled candidate lists and readout rows that name member and blocked tuples."""
+    from lpgnn_amd import twowl
+    from oracle import aggregation as agg, twowl_int
+    rng = np.random.default_rng(77)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for trial in range(10):
+        N, pe, pr, blocked = _tuple_case(rng, trial, n_lo=5, n_hi=60, e_hi=200, ep_hi=60)
+        E1, P = pe.shape[1], pe.shape[1] + pr.shape[1]
+        ei2 = twowl_int.get_ei2(N, pe, pr)
+        keep = np.ones(E1, bool)
+        if blocked is not None:
+            ei2 = twowl_int.blockei2(ei2, blocked)
+            keep[blocked] = False
+        edge1 = np.ascontiguousarray(pe[:, keep])
+        x_deg = np.bincount(edge1[0], minlength=N).astype(np.int64)
+        c2, d2 = [(16, 1), (24, 2), (32, 3), (8, 1)][trial % 4]
+        torch.manual_seed(trial)
+        mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=32, channels_2wl=c2, depth1=1 + trial % 2, depth2=d2)
+        with torch.no_grad():
+            for name, p in mod.named_parameters():
+                if name.endswith("mean_scale") or (name.endswith("weight") and p.dim() == 1):
+                    p.uniform_(0.6, 1.4)
+                elif name.endswith("bias"):
+                    p.uniform_(-0.3, 0.3)
+        mod = mod.to(dev).eval()
+        pos1 = np.concatenate([pe.T, pr.T], 0)
+        idx = np.concatenate([E1 + np.arange(pr.shape[1]), rng.integers(0, P, size=8)])
+        want = agg.localwl_forward(mod.export_params(), x_deg, edge1, pos1, idx, ei2)
+        scale = np.abs(want).max()
+        tg = twowl.tuple_graph(N, t(pe), t(pr))
+        if blocked is not None:                                    # through sample_block, as TwoWL/model/train.py:32 does
+            ei_new, x_new, tg = twowl.sample_block(t(blocked), N, t(pe), tg)
+            assert np.array_equal(_np(ei_new), edge1) and np.array_equal(_np(x_new), x_deg)
+            assert np.array_equal(_np(tg.materialize()), ei2)
+        outs = {}
+        for mode, small in (("node", True), ("node", False), ("operator", False), ("explicit", False)):
+            monkeypatch.setattr(twowl, "_IMPLICIT_MODE", "operator" if mode == "operator" else "node")
+            monkeypatch.setattr(twowl, "_SMALL_PATH", small)
+            mod.invalidate_plans()
+            with torch.no_grad():
+                o = mod(t(x_deg), t(edge1), t(pos1), t(idx), t(ei2) if mode == "explicit" else tg, True)
+            outs[mode, small] = _np(o).astype(np.float64)
+            assert np.abs(outs[mode, small] - want).max() <= TOL * scale, (trial, mode, small, np.abs(outs[mode, small] - want).max() / scale)
+
+
+def test_tuple_gcn_operator_arbitrary_input(dev):
+    """GCNConv(x, reverse(TupleGraph)[k]) for an arbitrary [P, C_in] input (the reference's own Seq calls the module
+    this way, TwoWL/model/model.py:77,92-96) against the fp64 GCNConv over the explicit orientation edges."""
+    from lpgnn_amd import nn as lnn, twowl
+    from oracle import aggregation as agg, twowl_int
+    rng = np.random.default_rng(12)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for trial in range(6):
+        N, pe, pr, blocked = _tuple_case(rng, trial, n_lo=5, n_hi=80, e_hi=300, ep_hi=80)
+        P = pe.shape[1] + pr.shape[1]
+        ei2 = twowl_int.get_ei2(N, pe, pr)
+        tg = twowl.tuple_graph(N, t(pe), t(pr))
+        if blocked is not None:
+            ei2 = twowl_int.blockei2(ei2, blocked)
+            tg = twowl.blockei2(tg, t(blocked))
+        cin, cout = [(16, 16), (40, 24), (7, 5)][trial % 3]
+        torch.manual_seed(trial)
+        conv = lnn.GCNConv(cin, cout).to(dev).eval()
+        with torch.no_grad():
+            conv.bias.uniform_(-0.5, 0.5)
+        x = rng.standard_normal((P, cin)).astype(np.float32)
+        e_a, e_r = twowl_int.reverse(ei2)
+        for orient, edges in zip(twowl.reverse(tg), (e_a, e_r)):
+            with torch.no_grad():
+                got = _np(conv(t(x), orient)).astype(np.float64)
+            w, b = _np(conv.lin.weight).astype(np.float64), _np(conv.bias).astype(np.float64)
+            want = agg.gcn_conv(x, edges, w, b)
+            ei_n, wn = agg.gcn_norm(edges, P)
+            mag = np.zeros_like(want)
+            np.add.at(mag, ei_n[1], (np.abs(x.astype(np.float64)) @ np.abs(w).T)[ei_n[0]] * wn[:, None])
+            assert np.all(np.abs(got - want) <= TOL * (mag + np.abs(b)[None, :]) + 1e-30), (trial, orient.orient)
+
+
+def test_localwl_implicit_large_graph(dev, monkeypatch):
+    """a graph far beyond what the explicit tuple graph allows (|V| = 60 K, 0.8 M graph tuples with hubs of > 1000
+    neighbours: E2 would be ~ 10^8-10^9 edges): the per-node form (A x through the CSR SpMM, the partial-sum fold, the
+    generic 1-WL stage) against the fp64 collapsed oracle -- itself pinned to the explicit form by
+    tests/test_twowl_collapsed.py -- at 1e-5 of the logit scale, and bitwise reproducible."""
+    from lpgnn_amd import twowl
+    from oracle import aggregation as agg, twowl_int
+    rng = np.random.default_rng(3)
+    N, E, Ep = 60_000, 400_000, 20_000
+    w = 1.0 / (np.arange(N) + 10.0) ** 0.9
+    und = rng.choice(N, size=(2, E), p=w / w.sum())
+    pe = twowl_int.double(und)
+    pr = twowl_int.double(rng.integers(0, N, size=(2, Ep // 2)))
+    x_deg = np.bincount(pe[0], minlength=N).astype(np.int64)
+    assert x_deg.max() > 1000
+    torch.manual_seed(9)
+    mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=64, channels_2wl=32, depth1=1, depth2=2).to(dev).eval()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tg = twowl.tuple_graph(N, t(pe), t(pr))
+    idx = np.concatenate([pe.shape[1] + np.arange(Ep), rng.integers(0, pe.shape[1], size=64)])
+    monkeypatch.setattr(twowl, "_IMPLICIT_MODE", "node")
+    with torch.no_grad():
+        got = mod(t(x_deg), t(pe), tg.pos1, t(idx), tg, True)
+        again = mod(t(x_deg), t(pe), tg.pos1, t(idx), tg, True)
+    assert torch.equal(got, again)
+    want = agg.localwl_forward_collapsed(mod.export_params(), x_deg, pe, pe, pr, idx, N)
+    err = np.abs(_np(got).astype(np.float64) - want).max() / np.abs(want).max()
+    print(f"implicit TwoWL on |V| = {N}, {pe.shape[1]} graph tuples: max |logit error| {err:.1e} of the logit scale")
+    assert err <= TOL
