@@ -166,11 +166,112 @@ def twowl_forward_bench(device, iters=50):
         cap()
     torch.cuda.synchronize()
     dt = (time.time() - t0) / (4 * iters)
+    tg = twowl.tuple_graph(620, ei, pred)                             # the same tuple graph as a structured handle
+    mod.invalidate_plans()
+    imp = {}
+    try:
+        ref = twowl.test_forward(mod, x_deg, ei, pos1, y_len, ei2)
+        got = twowl.test_forward(mod, x_deg, ei, pos1, y_len, tg)
+        imp["max_abs_diff_vs_explicit"] = float((ref - got).abs().max())
+        ms = _time_ms(lambda: twowl.test_forward(mod, x_deg, ei, pos1, y_len, tg), 4 * iters, warm=5)
+        cap2 = twowl.CapturedForward(mod, x_deg, ei, pos1, y_len, tg)
+        ms_g = _time_ms(cap2, 4 * iters, warm=5)
+        imp.update({"us_per_forward_eager": ms * 1e3, "us_per_forward": ms_g * 1e3,
+                    "scored_edges_per_s_eager": (y_len // 2) / (ms * 1e-3), "scored_edges_per_s": (y_len // 2) / (ms_g * 1e-3),
+                    "launches": 4})
+    except Exception as e:
+        imp["error"] = repr(e)
     return {"workload": "fb-pages-food TwoWL test-split scoring forward fp32 (configs[1]): N=620 E1=3480 P=4252 "
                         "E2=69525 B=386, C1=256 C2=32 depth 1/1", "scored_edges": y_len // 2,
             "us_per_forward": dt * 1e6, "scored_edges_per_s": (y_len // 2) / dt,
             "us_per_forward_eager": dt_eager * 1e6, "scored_edges_per_s_eager": (y_len // 2) / dt_eager, "mode": "hipGraph replay of the whole forward",
+            "implicit": imp,
             "reference_recorded_s_per_forward": [0.0698, 0.1361]}
+
+
+def _time_ms(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def twowl_scaled_bench(device, iters=20, n_pairs=100_000):
+    """TwoWL beyond toy graphs: the "ogbl-collab"-shaped stand-in of configs[2] (RMAT |V| = 235 868, 1 285 465
+    undirected edges, seed 1 -> 2.57 M directed graph tuples) + 100 K candidate pairs (200 K candidate tuples), model
+    defaults C1 = 256, C2 = 32, depth 1/1 (TwoWL/model/model.py:13-16).  The explicit tuple graph of
+    TwoWL/utils.py:36-45 would have E2 = sum deg^2 edges here (reported as e2_explicit); the forward runs over the
+    structured handle (twowl.TupleGraph) in its two forms: per-node sums all the way ("node"), and GCNConv per
+    orientation on materialised [P, C] rows ("operator": group sums + broadcast, what a module-by-module caller gets)."""
+    from lpgnn_amd import ops, twowl
+    N, E, C1, C2 = 235_868, 1_285_465, 256, 32
+    und = rmat_edges(N, E, 1, device)
+    pos_edge = twowl.double(und)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(2)
+    pred_edge = twowl.double(torch.randint(0, N, (2, n_pairs), generator=gen, device=device))
+    del und
+    x_deg = twowl.degree(pos_edge, N)
+    tg = twowl.tuple_graph(N, pos_edge, pred_edge)
+    E1, Ep = pos_edge.shape[1], pred_edge.shape[1]
+    P = E1 + Ep
+    idx = E1 + torch.arange(Ep, device=device)
+    torch.manual_seed(0)
+    mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=C1, channels_2wl=C2).to(device).eval()
+    deg = x_deg.double()
+    starts = twowl.degree(torch.stack([pred_edge[1], pred_edge[0]]), N).double() + deg
+    e2 = int((deg * starts).sum().item())
+    out = {"workload": f"collab-shaped TwoWL scoring forward fp32: |V|={N}, {E1} graph tuples + {Ep} candidate tuples "
+                       f"({n_pairs} scored edges), C1={C1} C2={C2} depth 1/1; structured tuple graph (no ei2)",
+           "scored_edges": n_pairs, "P": P, "e2_explicit": e2}
+    res = {}
+    with torch.no_grad():
+        for mode in ("node", "operator"):
+            twowl._IMPLICIT_MODE = mode
+            try:
+                fwd = lambda: mod(x_deg, pos_edge, tg.pos1, idx, tg, True)
+                ref = fwd()
+                ms = _time_ms(fwd, iters)
+                x1 = mod._input_features(x_deg)
+                for conv1 in mod.conv1s:
+                    x1 = conv1(x1, pos_edge)
+                if mode == "node":
+                    stage = lambda: mod._two_wl_node(x1, tg, idx)
+                else:
+                    e_a, e_r = tg.reverse()
+
+                    def stage():
+                        h = ops.pair_gather_mul(x1, tg.pos1)
+                        for i in range(len(mod.conv2s)):
+                            h = mod._both_orientations(mod.conv2s[i], mod.conv2s_r[i], h, e_a, e_r)
+                        return ops.pair_readout(h, idx, mod.pred.weight, mod.pred.bias)
+                assert torch.equal(stage(), ref)
+                ms2 = _time_ms(stage, iters)
+                res[mode] = {"ms_per_forward": ms, "scored_edges_per_s": n_pairs / (ms * 1e-3), "two_wl_stage_ms": ms2,
+                             "one_wl_stage_ms": ms - ms2}
+                if mode == "operator":
+                    # row passes over [P, C2] fp32 in the 2-WL stage: pair product (1 write), per orientation the group
+                    # sums (1 read) and the broadcast (1 write), GraphNorm (2 reads, 1 write; the second also reads the sum)
+                    passes = 1 + 2 * 2 + 3 + 4
+                    gbs = passes * P * C2 * 4 / (ms2 * 1e-3) / 1e9
+                    res[mode].update({"row_passes": passes, "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS})
+                else:
+                    # what the per-node form must move: A x over the member adjacency (E1 gathered rows of C2 floats
+                    # + indices), node tables and the candidates' rows; everything but the gather is N- or Q-sized
+                    alg = E1 * (C2 * 4 + 4) + N * C2 * 4 * 4 + Ep * C2 * 4 * 3
+                    res[mode].update({"algorithmic_bytes": alg, "achieved_GBs": alg / (ms2 * 1e-3) / 1e9,
+                                      "bound": "infinity-cache (x1 is 30 MB: the gather never leaves the die)"})
+            except Exception as e:
+                res[mode] = {"error": repr(e)}
+            finally:
+                twowl._IMPLICIT_MODE = "node"
+    out.update(res.get("node", {}))
+    out["operator_form"] = res.get("operator")
+    return out
 
 
 def seal_forward_bench(device, iters=10):
@@ -622,7 +723,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(d)
             if not args.no_twowl:
-                for key, fn in (("twowl", twowl_forward_bench), ("seal", seal_forward_bench)):
+                for key, fn in (("twowl", twowl_forward_bench), ("twowl_scaled", twowl_scaled_bench), ("seal", seal_forward_bench)):
                     try:
                         out[key] = fn(device)
                     except Exception as e:   # secondary figures must never take the headline down
@@ -641,7 +742,10 @@ def main():
               "seal_collab_100k_fp32": ((out.get("seal_sharded") or {}).get("fp32") or {}).get("scored_edges_per_s"),
               "seal_fb": (out.get("seal") or {}).get("scored_edges_per_s"),
               "twowl_fb": (out.get("twowl") or {}).get("scored_edges_per_s"),
-              "twowl_fb_eager": (out.get("twowl") or {}).get("scored_edges_per_s_eager")}
+              "twowl_fb_eager": (out.get("twowl") or {}).get("scored_edges_per_s_eager"),
+              "twowl_fb_implicit_eager": ((out.get("twowl") or {}).get("implicit") or {}).get("scored_edges_per_s_eager"),
+              "twowl_collab_100k": (out.get("twowl_scaled") or {}).get("scored_edges_per_s"),
+              "twowl_collab_100k_operator_form": ((out.get("twowl_scaled") or {}).get("operator_form") or {}).get("scored_edges_per_s")}
         out["scored_edges_per_s"] = {k: v for k, v in sc.items() if v is not None}
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -274,8 +274,8 @@ int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C
 /* The whole small-graph scoring forward of LocalWLNet (TwoWL/model/model.py:68-84; the timed call of
  * TwoWL/model/train.py:54-60) as ONE call: `block` (HOST memory, n_words int64 words) lists the forward's launches in
  * order as { op, a_0 .. a_{k-1} } -- op 1: lpg_embedding_graphnorm_f32 (k = 12), 2: lpg_small_linear_t_f32 (27),
- * 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23), 5: lpg_small_gcn_embed_f32 (21), 6: lpg_tuple_layer_f32 (29),
- * 7: lpg_tuple_readout_f32 (30); a_i = that entry point's i-th argument (pointers and
+ * 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23), 5: lpg_small_gcn_embed_f32 (21), 6: lpg_tuple_layer_f32 (19),
+ * 7: lpg_tuple_readout_f32 (30), 8: lpg_tuple_ax_small_f32 (15); a_i = that entry point's i-th argument (pointers and
  * integers as they are, `float eps` as the bit pattern of a double; the trailing stream argument is left out).  Every
  * launch goes through the same entry point as the one-by-one path and is enqueued on `stream`: same kernels, same
  * results, one host call per forward instead of six (the forward is launch-bound: 205 -> ~60 us eager).
@@ -324,10 +324,12 @@ int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8
  *   node, n_node for a non-member (scatter indices of the operator form); head (int32[4], device): [0] = Q,
  *   [1] = bit 0: layout conditions violated (use the explicit tuple graph), bit 1: a node id out of range (also
  *   err_flag).  No host sync.
+ * lpg_tuple_ax_small_f32 (graphs whose longest member row is short; a workgroup per node): x1n = GraphNorm(y1)
+ *   (+ ReLU) with the column sums in_part [in_rb][2][C] the small-graph conv1 leaves (NULL: x1n = y1) and ax = A x1n
+ *   over the member adjacency (rowptr, col).  Big graphs use lpg_csr_spmm_f32 for A x.
  * lpg_tuple_layer_f32: one 2-WL layer, both orientations (C <= 32).  mode 1 (first layer): x = the 1-WL output
- *   [n_node, C] (model.py:73; with in_part != NULL still un-normalised: GraphNorm (+ ReLU) of the small-graph conv1
- *   is applied on load, part layout [in_rb][2][C]), ax = A x [n_node, C] or NULL = summed inside from (rowptr, col);
- *   the pair product (model.py:75) never exists for member tuples: their group sum is x[i] * (A x)[i].  mode 2:
+ *   [n_node, C] (model.py:73), ax = A x [n_node, C]; the pair product (model.py:75) never exists for member tuples:
+ *   their group sum is x[i] * (A x)[i].  mode 2:
  *   x = (F_a | F_r) [n_node, 2C] from lpg_tuple_apply_f32, ax = A x [n_node, 2C], hq_prev [Q, C].
  *   Writes t_node [n_node, 2C] = (T_a | T_r) (may be NULL), y_q [Q, 2C] = the non-member rows (bias added) and
  *   part [n_blocks][2][64] (fp64 sums of y and y^2 over ALL P rows, column = orientation * 32 + c), n_blocks =
@@ -346,13 +348,14 @@ int lpg_tuple_plan_build(const int64_t* pos_edge, int64_t E1, const int64_t* pre
                          int64_t* seg_r, int32_t* head, void* workspace, int64_t workspace_bytes,
                          int32_t* err_flag, void* stream);
 int64_t lpg_tuple_layer_blocks(int64_t n_node, int64_t Q);
+int lpg_tuple_ax_small_f32(int64_t n_node, int64_t C, const float* y1, int64_t ldy,
+                           const int64_t* rowptr, const int32_t* col, const double* in_part,
+                           const float* in_gw, const float* in_gb, const float* in_gms, int64_t in_rb,
+                           int in_relu, float in_eps, float* x1n, float* ax, void* stream);
 int lpg_tuple_layer_f32(int mode, int64_t n_node, int64_t Q, int64_t C, const float* x, int64_t ldx,
-                        const float* ax, int64_t ldax, const int64_t* rowptr, const int32_t* col,
-                        const float* hq_prev, const int32_t* cnt, const int32_t* qinfo,
-                        const float* w_a, const float* w_r, const float* b_a, const float* b_r,
-                        float* t_node, float* y_q, double* part, int64_t n_blocks,
-                        const double* in_part, const float* in_gw, const float* in_gb,
-                        const float* in_gms, int64_t in_rb, int in_relu, int64_t in_n, float in_eps,
+                        const float* ax, int64_t ldax, const float* hq_prev, const int32_t* cnt,
+                        const int32_t* qinfo, const float* w_a, const float* w_r, const float* b_a,
+                        const float* b_r, float* t_node, float* y_q, double* part, int64_t n_blocks,
                         void* stream);
 int lpg_tuple_fold_f64(const double* part, int64_t n_in, double* out, int64_t n_out, void* stream);
 int lpg_tuple_apply_f32(int64_t n_node, int64_t Q, int64_t C, const float* t_node, const float* y_q,

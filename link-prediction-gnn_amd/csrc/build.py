@@ -17,6 +17,12 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-DNDEBUG"]
 
 
+# per-file additions.  tuple_wl.hip: hipcc's SLP vectoriser pairs the products of two rows into v_pk_fma_f32, which wants
+# every weight duplicated in a register pair -- 64 registers for 32 weights, 187 VGPRs and 60 spills at the kernel's
+# 128-register bound; without it 90-103 VGPRs, no scratch.
+EXTRA = {"tuple_wl.hip": ["-fno-slp-vectorize"]}
+
+
 def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
@@ -49,7 +55,7 @@ def build(force=False, verbose=True, jobs=None, tuning=False):
 
     def cc(pair):
         src, obj = pair
-        cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc()] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 

@@ -770,7 +770,7 @@ LPG_EXPORT int lpg_twowl_forward_small(const int64_t* block, int64_t n_words, vo
   while (i < n_words) {
     const int64_t op = block[i];
     const int64_t* a = block + i + 1;
-    const int64_t need = op == 1 ? 12 : op == 2 ? 27 : op == 3 ? 20 : op == 4 ? 23 : op == 5 ? 21 : op == 6 ? 29 : op == 7 ? 30 : -1;
+    const int64_t need = op == 1 ? 12 : op == 2 ? 27 : op == 3 ? 20 : op == 4 ? 23 : op == 5 ? 21 : op == 6 ? 19 : op == 7 ? 30 : op == 8 ? 15 : -1;
     LPG_REQUIRE(need > 0 && i + 1 + need <= n_words, "twowl_forward_small: malformed block at word %lld (op %lld)",
                 (long long)i, (long long)op);
     int rc = LPG_OK;
@@ -798,11 +798,13 @@ LPG_EXPORT int lpg_twowl_forward_small(const int64_t* block, int64_t n_words, vo
                                    wp<int32_t>(a[20]), stream);
     } else if (op == 6) {
       rc = lpg_tuple_layer_f32(static_cast<int>(a[0]), a[1], a[2], a[3], wp<const float>(a[4]), a[5], wp<const float>(a[6]), a[7],
-                               wp<const int64_t>(a[8]), wp<const int32_t>(a[9]), wp<const float>(a[10]), wp<const int32_t>(a[11]),
-                               wp<const int32_t>(a[12]), wp<const float>(a[13]), wp<const float>(a[14]), wp<const float>(a[15]),
-                               wp<const float>(a[16]), wp<float>(a[17]), wp<float>(a[18]), wp<double>(a[19]), a[20],
-                               wp<const double>(a[21]), wp<const float>(a[22]), wp<const float>(a[23]), wp<const float>(a[24]),
-                               a[25], static_cast<int>(a[26]), a[27], wf(a[28]), stream);
+                               wp<const float>(a[8]), wp<const int32_t>(a[9]), wp<const int32_t>(a[10]), wp<const float>(a[11]),
+                               wp<const float>(a[12]), wp<const float>(a[13]), wp<const float>(a[14]), wp<float>(a[15]),
+                               wp<float>(a[16]), wp<double>(a[17]), a[18], stream);
+    } else if (op == 8) {
+      rc = lpg_tuple_ax_small_f32(a[0], a[1], wp<const float>(a[2]), a[3], wp<const int64_t>(a[4]), wp<const int32_t>(a[5]),
+                                  wp<const double>(a[6]), wp<const float>(a[7]), wp<const float>(a[8]), wp<const float>(a[9]),
+                                  a[10], static_cast<int>(a[11]), wf(a[12]), wp<float>(a[13]), wp<float>(a[14]), stream);
     } else if (op == 7) {
       rc = lpg_tuple_readout_f32(a[0], a[1], a[2], a[3], a[4], wp<const int64_t>(a[5]), wp<const float>(a[6]),
                                  wp<const float>(a[7]), wp<const int32_t>(a[8]), wp<const int32_t>(a[9]), wp<const double>(a[10]),

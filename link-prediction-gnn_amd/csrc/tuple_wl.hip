@@ -139,14 +139,25 @@ struct TwNorm {          // statistics of one 2-WL layer: part [n_part][2][64] (
   float eps_a, eps_r;
   int n_part, relu_a, relu_r;
 };
-__device__ __forceinline__ TwCoef tw_coef(const TwNorm& nm, int side, int c) {
-  const int col = side * 32 + c;
-  double s = 0.0, s2 = 0.0;
-#pragma unroll 4
-  for (int g = 0; g < nm.n_part; ++g) {                        // fixed order
-    s += nm.part[(static_cast<int64_t>(g) * 2 + 0) * 64 + col];
-    s2 += nm.part[(static_cast<int64_t>(g) * 2 + 1) * 64 + col];
+// the 128 column sums (sum y | sum y^2 for 64 columns) of a layer, folded by a whole 256-thread workgroup: thread
+// (p, h) adds the partial blocks h, h + 2, ... of sum p (all loads in flight at once), the two halves meet in LDS in a
+// fixed order.  Call from every thread of the workgroup; `sums` = 256 doubles of LDS.
+__device__ __forceinline__ void tw_fold_block(const double* __restrict__ part, int n_part, int first, int step, double* sums) {
+  const int p = threadIdx.x & 127, h = threadIdx.x >> 7;
+  double acc = 0.0;
+  int g = first + h * step;
+  for (; g + 6 * step < n_part; g += 8 * step) {
+    const double v0 = part[static_cast<int64_t>(g) * 128 + p], v1 = part[static_cast<int64_t>(g + 2 * step) * 128 + p];
+    const double v2 = part[static_cast<int64_t>(g + 4 * step) * 128 + p], v3 = part[static_cast<int64_t>(g + 6 * step) * 128 + p];
+    acc += v0; acc += v1; acc += v2; acc += v3;
   }
+  for (; g < n_part; g += 2 * step) acc += part[static_cast<int64_t>(g) * 128 + p];
+  sums[h * 128 + p] = acc;
+  __syncthreads();
+}
+__device__ __forceinline__ TwCoef tw_coef(const TwNorm& nm, const double* sums, int side, int c) {
+  const int col = side * 32 + c;
+  const double s = sums[col] + sums[128 + col], s2 = sums[64 + col] + sums[128 + 64 + col];
   const float* gw = side ? nm.gw_r : nm.gw_a;
   const float* gb = side ? nm.gb_r : nm.gb_a;
   const float* gms = side ? nm.gms_r : nm.gms_a;
@@ -170,15 +181,55 @@ __device__ __forceinline__ TwCoef tw_coef_in(const TwNormIn& nm, int C, int c) {
                            nm.gms ? nm.gms[c] : 1.f, nm.eps, nm.relu);
 }
 
-// value of a member row of node i: every member tuple of the group shares it
-__device__ __forceinline__ float tw_member(float t, int cn, float bias) { return t / static_cast<float>(cn) + bias; }
+// value of a member row of node i: every member tuple of the group shares it.  One v_rcp_f32 (1 ulp) instead of the
+// IEEE division sequence; every kernel that needs the value goes through here, so statistics and rows agree bit for bit.
+__device__ __forceinline__ float tw_member(float t, int cn, float bias) {
+  return fmaf(t, __builtin_amdgcn_rcpf(static_cast<float>(cn)), bias);
+}
+
+// ------------------------------------------------------------------------------------------------ A x on small graphs
+// x1n = GraphNorm(y1) (+ ReLU; the small-graph conv1 leaves its output un-normalised with per-row-block column sums)
+// and ax = A x1n, a 256-thread workgroup per node row: its eight 32-lane slots take the row's entries round robin,
+// eight gathers in flight each, and meet in LDS in a fixed order.  (Summing the member row inside the layer kernel
+// instead -- one launch less -- cost 33-58 us on fb-pages-food: a candidate row on a hub walks 109 entries alone.)
+__global__ __launch_bounds__(kBlock) void tw_ax_small_kernel(int C, const float* __restrict__ y1, int64_t ldy,
+                                                             const int64_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col, const TwNormIn nin,
+                                                             float* __restrict__ x1n, float* __restrict__ ax) {
+  __shared__ float red[8][32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int slot = wv * 2 + (lane >> 5), c = lane & 31;
+  const int cc = c < C ? c : C - 1;
+  TwCoef cin{0.f, 1.f, 0.f, 0};
+  if (nin.part) cin = tw_coef_in(nin, C, cc);
+  const int64_t i = blockIdx.x;
+  const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+  float acc = 0.f;
+  for (int64_t e = e0 + slot; e < e1; e += 64) {             // entries e, e + 8, ..., e + 56 of this slot
+    int cj[8];
+    float t8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cj[u] = col[e + 8 * u < e1 ? e + 8 * u : e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t8[u] = tw_apply(cin, y1[static_cast<int64_t>(cj[u]) * ldy + cc]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += e + 8 * u < e1 ? t8[u] : 0.f;
+  }
+  red[slot][c] = acc;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < C) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sacc += red[k][c];
+    ax[i * C + c] = sacc;
+    x1n[i * C + c] = tw_apply(cin, y1[i * ldy + c]);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ one 2-WL layer
 struct TwLayerArgs {
-  const float* x;        // MODE 1: x1 [n, C] (the 1-WL output, or un-normalised + nin); MODE 2: FF [n, 2C] = (F_a | F_r)
-  const float* ax;       // MODE 1: A x1 [n, C] (null with INLINE); MODE 2: A FF [n, 2C]
-  const int64_t* rowptr; // member adjacency (INLINE only)
-  const int32_t* col;
+  const float* x;        // MODE 1: x1 [n, C] (the 1-WL output); MODE 2: FF [n, 2C] = (F_a | F_r)
+  const float* ax;       // MODE 1: A x1 [n, C]; MODE 2: A FF [n, 2C]
   const float* hq_prev;  // MODE 2: the non-member rows of the previous layer [Q, C]
   const int32_t* cnt;    // [n] members starting (= ending) at a node
   const int32_t* qinfo;  // [Q][4] = (start, end, node_r, tuple id)
@@ -186,115 +237,157 @@ struct TwLayerArgs {
   float* t_node;         // [n, 2C] = (T_a | T_r), may be null
   float* y_q;            // [Q, 2C]
   double* part;          // [gridDim.x][2][64]
-  TwNormIn nin;
   int64_t ldx, ldax;
-  int n_node, Q, C;
+  int n_node, Q, C, tile;
 };
 
-template <int MODE, bool INLINE, bool DEFER>
+constexpr int kTwRows = 4;                 // rows a wave keeps in flight
+__device__ __forceinline__ float rl_f(float v, int lane) {      // v_readlane_b32 of a float (the builtin is typed int)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// A wave owns tiles of `tile` (<= 64) consecutive node rows or non-member rows: lane j reads row j's descriptors
+// (member count / (start, end, node_r)) with one coalesced load and derives the row's two scale factors, then the rows
+// go through in groups of kTwRows with every feature-row load of the group issued before anything is computed -- a row
+// is a chain of dependent round trips (descriptor -> feature rows -> product), and a wave that walks them one at a
+// time spends its life waiting (first version: 230 us for 436 K rows).
+template <int MODE>
 __global__ __launch_bounds__(kTwBlock) void tw_layer_kernel(const TwLayerArgs a) {
-  __shared__ float sv[kTwWaves][64];
+  __shared__ float sv[kTwWaves][kTwRows][64];
   __shared__ double sred[kTwWaves][2][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int side = lane >> 5, c = lane & 31, C = a.C;
   const bool live = c < C;
   const int cc = live ? c : C - 1;
-  float w[32];
-  {
-    const float* wm = side ? a.w_r : a.w_a;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      const float v = wm[cc * C + (k < C ? k : 0)];
-      w[k] = (live && k < C) ? v : 0.f;
-    }
+  // W_a, W_r -> LDS with coalesced loads (rows padded to 33 words: lane c reads row c conflict-free), then each lane's
+  // row into registers.  Read straight from global memory, lane c walking row c, every load instruction touches 64
+  // different lines and the 16 waves of the workgroup queue behind each other: 13 of the 18 us the kernel took on
+  // fb-pages-food.
+  __shared__ float sw[2][32][33];
+  for (int i = threadIdx.x; i < 2 * C * C; i += kTwBlock) {
+    const int sd = i >= C * C, rem = i - sd * C * C;
+    sw[sd][rem / C][rem % C] = (sd ? a.w_r : a.w_a)[rem];
   }
-  const float bias = (side ? a.b_r : a.b_a)[cc];
-  TwCoef cin{0.f, 1.f, 0.f, 0};
-  if (DEFER) cin = tw_coef_in(a.nin, C, cc);
-  auto ldx1 = [&](int64_t j) -> float {                     // element cc of row j of x1 (MODE 1)
-    const float v = a.x[j * a.ldx + cc];
-    return DEFER ? tw_apply(cin, v) : v;
-  };
-  auto row_sum = [&](int64_t node, int first, int step) -> float {      // sum over the member row of `node`, entries first, first + step, ...
-    const int64_t e0 = a.rowptr[node], e1 = a.rowptr[node + 1];
-    float acc = 0.f;
-    int64_t e = e0 + first;
-    for (; e + 3 * step < e1; e += 4 * step) {
-      const int j0 = a.col[e], j1 = a.col[e + step], j2 = a.col[e + 2 * step], j3 = a.col[e + 3 * step];
-      const float v0 = ldx1(j0), v1 = ldx1(j1), v2 = ldx1(j2), v3 = ldx1(j3);
-      acc += v0; acc += v1; acc += v2; acc += v3;
-    }
-    for (; e < e1; e += step) acc += ldx1(a.col[e]);
-    return acc;
-  };
-  double s1 = 0.0, s2 = 0.0;
-  const int rows = a.n_node + a.Q;
-  const int gw = blockIdx.x * kTwWaves + wv, nw = gridDim.x * kTwWaves;
-  const int own = side * C + cc, oth = (1 - side) * C + cc;
-  for (int r = gw; r < rows; r += nw) {
-    float v;
-    int cn = 0, q = -1;
-    if (r < a.n_node) {
-      cn = a.cnt[r];
-      if (MODE == 1) {
-        float axv;
-        if (INLINE) {
-          axv = row_sum(r, side, 2);                        // the two halves take alternate entries
-          axv += __shfl_xor(axv, 32);
-        } else {
-          axv = a.ax[r * a.ldax + cc];
-        }
-        v = ldx1(r) * axv;
-      } else {
-        v = static_cast<float>(cn) * a.x[r * a.ldx + own] + a.ax[r * a.ldax + oth];
-      }
-    } else {
-      q = r - a.n_node;
-      const int4 inf = *reinterpret_cast<const int4*>(a.qinfo + 4 * static_cast<int64_t>(q));
-      const int node = side ? inf.z : inf.x;
-      const int cq = a.cnt[node];
-      const float cf = static_cast<float>(cq);
-      const float ca = cq > 0 ? 1.0f / sqrtf(cf * (cf + 1.0f)) : 0.f, cb = 1.0f / (cf + 1.0f);
-      float sx, h;
-      if (MODE == 1) {
-        const float xs = ldx1(inf.x), xe = ldx1(inf.y);
-        h = xs * xe;
-        const float xn = side ? ldx1(node) : xs;
-        const float axn = INLINE ? row_sum(node, 0, 1) : a.ax[static_cast<int64_t>(node) * a.ldax + cc];
-        sx = xn * axn;
-      } else {
-        h = a.hq_prev[static_cast<int64_t>(q) * C + cc];
-        sx = cf * a.x[static_cast<int64_t>(node) * a.ldx + own] + a.ax[static_cast<int64_t>(node) * a.ldax + oth];
-      }
-      v = ca * sx + cb * h;
-    }
-    sv[wv][lane] = live ? v : 0.f;
-    __builtin_amdgcn_wave_barrier();
-    const float4* pv = reinterpret_cast<const float4*>(&sv[wv][side * 32]);
-    float acc = 0.f;
+  __syncthreads();
+  float w[32];
 #pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) {
-      if (4 * k4 < C) {
-        const float4 t = pv[k4];
-        acc = fmaf(t.x, w[4 * k4 + 0], acc);
-        acc = fmaf(t.y, w[4 * k4 + 1], acc);
-        acc = fmaf(t.z, w[4 * k4 + 2], acc);
-        acc = fmaf(t.w, w[4 * k4 + 3], acc);
-      }
+  for (int k = 0; k < 32; ++k) w[k] = (live && k < C) ? sw[side][cc][k < C ? k : 0] : 0.f;
+  const float bias = (side ? a.b_r : a.b_a)[cc];
+  // 32-bit element offsets (the entry point checks that every operand has < 2^31 elements): one VGPR per address
+  const uint32_t ldx = static_cast<uint32_t>(a.ldx), ldax = static_cast<uint32_t>(a.ldax), C2 = 2u * C;
+  double s1 = 0.0, s2 = 0.0;
+  const int ts = a.tile;
+  const int nt_node = (a.n_node + ts - 1) / ts, nt_q = (a.Q + ts - 1) / ts;
+  const int gw = blockIdx.x * kTwWaves + wv, nw = gridDim.x * kTwWaves;
+  const uint32_t own = side * C + cc, oth = (1 - side) * C + cc;
+  const uint32_t xcol = MODE == 1 ? cc : own, acol = MODE == 1 ? cc : oth;
+  for (int tile = gw; tile < nt_node + nt_q; tile += nw) {
+    const bool isq = tile >= nt_node;
+    const int r0 = (isq ? tile - nt_node : tile) * ts;
+    const int left = (isq ? a.Q : a.n_node) - r0;
+    const int nr = left < ts ? left : ts;
+    const int jl = lane < nr ? lane : nr - 1;
+    // lane j <-> row r0 + j: node ids, member counts and the two factors of a non-member row per orientation
+    int d_s = r0 + jl, d_e = 0, d_nr = 0, d_cs, d_cr = 0;
+    float f_aa = 0.f, f_ba = 0.f, f_ar = 0.f, f_br = 0.f;
+    if (isq) {
+      const int4 inf = *reinterpret_cast<const int4*>(a.qinfo + 4u * static_cast<uint32_t>(r0 + jl));
+      d_s = inf.x; d_e = inf.y; d_nr = inf.z;
+      d_cr = a.cnt[d_nr];
     }
-    __builtin_amdgcn_wave_barrier();
-    if (q < 0) {
-      if (a.t_node && live) a.t_node[static_cast<int64_t>(r) * (2 * C) + side * C + c] = acc;
-      if (cn > 0 && live) {
-        const double m = static_cast<double>(tw_member(acc, cn, bias)), cd = static_cast<double>(cn);
-        s1 += cd * m;
-        s2 += cd * m * m;
+    d_cs = a.cnt[d_s];
+    if (isq) {
+      const float fs = static_cast<float>(d_cs), fr = static_cast<float>(d_cr);
+      f_aa = d_cs > 0 ? __builtin_amdgcn_rsqf(fs * (fs + 1.0f)) : 0.f;
+      f_ba = __builtin_amdgcn_rcpf(fs + 1.0f);
+      f_ar = d_cr > 0 ? __builtin_amdgcn_rsqf(fr * (fr + 1.0f)) : 0.f;
+      f_br = __builtin_amdgcn_rcpf(fr + 1.0f);
+    }
+    for (int j0 = 0; j0 < nr; j0 += kTwRows) {
+      float v[kTwRows];
+      int cn[kTwRows];
+      if (!isq) {
+        float xo[kTwRows], xa[kTwRows];
+#pragma unroll
+        for (int u = 0; u < kTwRows; ++u) {
+          const int j = j0 + u < nr ? j0 + u : nr - 1;
+          const uint32_t i = r0 + j;
+          cn[u] = __builtin_amdgcn_readlane(d_cs, j);
+          xo[u] = a.x[i * ldx + xcol];
+          xa[u] = a.ax[i * ldax + acol];
+        }
+#pragma unroll
+        for (int u = 0; u < kTwRows; ++u) v[u] = MODE == 1 ? xo[u] * xa[u] : fmaf(static_cast<float>(cn[u]), xo[u], xa[u]);
+      } else {
+        float h[kTwRows], xn[kTwRows], an[kTwRows], fa[kTwRows], fb[kTwRows];
+#pragma unroll
+        for (int u = 0; u < kTwRows; ++u) {
+          const int j = j0 + u < nr ? j0 + u : nr - 1;
+          // every readlane unconditional, the orientation picked by a select: written as side ? readlane : readlane
+          // hipcc branches per half-wave around each of them and drains vmcnt in between
+          const int s = __builtin_amdgcn_readlane(d_s, j), nrn = __builtin_amdgcn_readlane(d_nr, j);
+          const int cs_ = __builtin_amdgcn_readlane(d_cs, j), cr_ = __builtin_amdgcn_readlane(d_cr, j);
+          const float aa_ = rl_f(f_aa, j), ar_ = rl_f(f_ar, j), ba_ = rl_f(f_ba, j), br_ = rl_f(f_br, j);
+          const uint32_t node = side ? nrn : s;
+          cn[u] = side ? cr_ : cs_;
+          fa[u] = side ? ar_ : aa_;
+          fb[u] = side ? br_ : ba_;
+          if (MODE == 1) {
+            const int e = __builtin_amdgcn_readlane(d_e, j);
+            const float xs = a.x[static_cast<uint32_t>(s) * ldx + cc], xe = a.x[static_cast<uint32_t>(e) * ldx + cc];
+            h[u] = xs * xe;
+            xn[u] = a.x[node * ldx + cc];
+          } else {
+            h[u] = a.hq_prev[static_cast<uint32_t>(r0 + j) * C + cc];
+            xn[u] = a.x[node * ldx + own];
+          }
+          an[u] = a.ax[node * ldax + acol];
+        }
+#pragma unroll
+        for (int u = 0; u < kTwRows; ++u) {
+          const float sx = MODE == 1 ? xn[u] * an[u] : fmaf(static_cast<float>(cn[u]), xn[u], an[u]);
+          v[u] = fmaf(fa[u], sx, fb[u] * h[u]);
+        }
       }
-    } else if (live) {
-      const float y = acc + bias;
-      a.y_q[static_cast<int64_t>(q) * (2 * C) + side * C + c] = y;
-      s1 += static_cast<double>(y);
-      s2 += static_cast<double>(y) * static_cast<double>(y);
+#pragma unroll
+      for (int u = 0; u < kTwRows; ++u) sv[wv][u][lane] = live ? v[u] : 0.f;
+      __builtin_amdgcn_wave_barrier();
+      float acc[kTwRows];
+#pragma unroll
+      for (int u = 0; u < kTwRows; ++u) acc[u] = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        if (4 * k4 < C) {
+#pragma unroll
+          for (int u = 0; u < kTwRows; ++u) {
+            const float4 t = *reinterpret_cast<const float4*>(&sv[wv][u][side * 32 + 4 * k4]);
+            acc[u] = fmaf(t.x, w[4 * k4 + 0], acc[u]);
+            acc[u] = fmaf(t.y, w[4 * k4 + 1], acc[u]);
+            acc[u] = fmaf(t.z, w[4 * k4 + 2], acc[u]);
+            acc[u] = fmaf(t.w, w[4 * k4 + 3], acc[u]);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < kTwRows; ++u) {
+        if (j0 + u < nr && live) {
+          const uint32_t r = r0 + j0 + u;
+          if (!isq) {
+            if (a.t_node) a.t_node[r * C2 + own] = acc[u];
+            if (cn[u] > 0) {
+              const double m = static_cast<double>(tw_member(acc[u], cn[u], bias)), cd = static_cast<double>(cn[u]);
+              s1 += cd * m;
+              s2 += cd * m * m;
+            }
+          } else {
+            const float y = acc[u] + bias;
+            a.y_q[r * C2 + own] = y;
+            s1 += static_cast<double>(y);
+            s2 += static_cast<double>(y) * static_cast<double>(y);
+          }
+        }
+      }
     }
   }
   sred[wv][0][lane] = s1;
@@ -309,11 +402,11 @@ __global__ __launch_bounds__(kTwBlock) void tw_layer_kernel(const TwLayerArgs a)
   }
 }
 
-__global__ __launch_bounds__(128) void tw_fold_kernel(const double* __restrict__ part, int n_in, double* __restrict__ out) {
-  const int which = threadIdx.x >> 6, ln = threadIdx.x & 63;
-  double s = 0.0;
-  for (int g = blockIdx.x; g < n_in; g += gridDim.x) s += part[(static_cast<int64_t>(g) * 2 + which) * 64 + ln];
-  out[(static_cast<int64_t>(blockIdx.x) * 2 + which) * 64 + ln] = s;
+// partial blocks blockIdx, blockIdx + gridDim, ... -> one
+__global__ __launch_bounds__(kBlock) void tw_fold_kernel(const double* __restrict__ part, int n_in, double* __restrict__ out) {
+  __shared__ double sums[256];
+  tw_fold_block(part, n_in, blockIdx.x, gridDim.x, sums);
+  if (threadIdx.x < 128) out[static_cast<int64_t>(blockIdx.x) * 128 + threadIdx.x] = sums[threadIdx.x] + sums[128 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------ between two layers
@@ -322,11 +415,13 @@ __global__ __launch_bounds__(kBlock) void tw_apply_kernel(int n_node, int Q, int
                                                           const TwNorm nm, const float* __restrict__ b_a,
                                                           const float* __restrict__ b_r, float* __restrict__ ff,
                                                           float* __restrict__ hq) {
+  __shared__ double sums[256];
+  tw_fold_block(nm.part, nm.n_part, 0, 1, sums);
   const int lane = threadIdx.x & 63;
   const int side = lane >> 5, c = lane & 31;
   const bool live = c < C;
   const int cc = live ? c : C - 1;
-  const TwCoef co = tw_coef(nm, side, cc);
+  const TwCoef co = tw_coef(nm, sums, side, cc);
   const float bias = (side ? b_r : b_a)[cc];
   const int gw = (blockIdx.x * kBlock + threadIdx.x) >> 6, nw = (gridDim.x * kBlock) >> 6;
   for (int r = gw; r < n_node + Q; r += nw) {
@@ -355,11 +450,13 @@ __global__ __launch_bounds__(kBlock) void tw_readout_kernel(int n_node, int Q, i
                                                             const float* __restrict__ b_r, const int64_t* __restrict__ idx,
                                                             int B, const float* __restrict__ w, const float* __restrict__ b0,
                                                             float* __restrict__ out, int32_t* err_flag) {
+  __shared__ double sums[256];
+  tw_fold_block(nm.part, nm.n_part, 0, 1, sums);
   const int lane = threadIdx.x & 63;
   const int t = lane >> 5, c = lane & 31;
   const bool live = c < C;
   const int cc = live ? c : C - 1;
-  const TwCoef ca = tw_coef(nm, 0, cc), cr = tw_coef(nm, 1, cc);
+  const TwCoef ca = tw_coef(nm, sums, 0, cc), cr = tw_coef(nm, sums, 1, cc);
   const float ba = b_a[cc], br = b_r[cc], wc = live ? w[cc] : 0.f, bb = b0 ? b0[0] : 0.f;
   const int gw = (blockIdx.x * kBlock + threadIdx.x) >> 6, nw = (gridDim.x * kBlock) >> 6;
   for (int j = gw; j < B; j += nw) {
@@ -408,7 +505,8 @@ __global__ __launch_bounds__(kBlock) void tw_bcast_kernel(int64_t P, int C, int 
       o = tw_member(t, cn, bi);
     } else {
       const float cf = static_cast<float>(cn);
-      o = (cn > 0 ? t / sqrtf(cf * (cf + 1.0f)) : 0.f) + hq[static_cast<int64_t>(q) * ldh + c] / (cf + 1.0f) + bi;
+      o = (cn > 0 ? t * __builtin_amdgcn_rsqf(cf * (cf + 1.0f)) : 0.f) +
+          hq[static_cast<int64_t>(q) * ldh + c] * __builtin_amdgcn_rcpf(cf + 1.0f) + bi;
     }
     y[b * ldy + c] = o;
   }
@@ -468,46 +566,66 @@ LPG_EXPORT int lpg_tuple_plan_build(const int64_t* pos_edge, int64_t E1, const i
   return check_launch("tuple_plan_build");
 }
 
+namespace {
+// rows per tile: about 4096 tiles (16 waves on each of 256 CUs), between one group of rows and a wave's 64 lanes
+int tw_tile(int64_t n_node, int64_t Q) {
+  int t = kTwRows;
+  while (t < 64 && (n_node + Q) > int64_t(4096) * t) t *= 2;
+  return t;
+}
+int64_t tw_blocks(int64_t n_node, int64_t Q) {
+  const int t = tw_tile(n_node, Q);
+  const int64_t g = ceil_div(ceil_div(n_node, t) + ceil_div(Q, t), kTwWaves);
+  return g < 1 ? 1 : (g > kTwMaxBlocks ? kTwMaxBlocks : g);
+}
+}  // namespace
+
 LPG_EXPORT int64_t lpg_tuple_layer_blocks(int64_t n_node, int64_t Q) {
   if (n_node < 0 || Q < 0) return LPG_E_INVALID;
-  const int64_t g = ceil_div(n_node + Q, kTwWaves * 2);          // two rows per wave on the reference's own graphs
-  return g < 1 ? 1 : (g > kTwMaxBlocks ? kTwMaxBlocks : g);
+  return tw_blocks(n_node, Q);
+}
+
+LPG_EXPORT int lpg_tuple_ax_small_f32(int64_t n_node, int64_t C, const float* y1, int64_t ldy, const int64_t* rowptr,
+                                      const int32_t* col, const double* in_part, const float* in_gw, const float* in_gb,
+                                      const float* in_gms, int64_t in_rb, int in_relu, float in_eps, float* x1n, float* ax,
+                                      void* stream) {
+  LPG_REQUIRE(n_node >= 1 && n_node < (int64_t(1) << 24) && C >= 1 && C <= 32 && ldy >= C, "tuple_ax_small: bad sizes");
+  LPG_REQUIRE(y1 && rowptr && col && x1n && ax, "tuple_ax_small: null pointer");
+  LPG_REQUIRE(!in_part || (in_rb >= 1 && in_rb <= 64), "tuple_ax_small: bad deferred-norm arguments");
+  const TwNormIn nin{in_part, in_gw, in_gb, in_gms, static_cast<int>(in_rb), in_relu, static_cast<int>(n_node), in_eps};
+  hipLaunchKernelGGL(tw_ax_small_kernel, dim3(static_cast<unsigned>(n_node)), dim3(kBlock), 0, as_stream(stream),
+                     static_cast<int>(C), y1, ldy, rowptr, col, nin, x1n, ax);
+  return check_launch("tuple_ax_small");
 }
 
 LPG_EXPORT int lpg_tuple_layer_f32(int mode, int64_t n_node, int64_t Q, int64_t C, const float* x, int64_t ldx, const float* ax,
-                                   int64_t ldax, const int64_t* rowptr, const int32_t* col, const float* hq_prev,
-                                   const int32_t* cnt, const int32_t* qinfo, const float* w_a, const float* w_r,
-                                   const float* b_a, const float* b_r, float* t_node, float* y_q, double* part,
-                                   int64_t n_blocks, const double* in_part, const float* in_gw, const float* in_gb,
-                                   const float* in_gms, int64_t in_rb, int in_relu, int64_t in_n, float in_eps, void* stream) {
+                                   int64_t ldax, const float* hq_prev, const int32_t* cnt, const int32_t* qinfo,
+                                   const float* w_a, const float* w_r, const float* b_a, const float* b_r, float* t_node,
+                                   float* y_q, double* part, int64_t n_blocks, void* stream) {
   LPG_REQUIRE((mode == 1 || mode == 2) && n_node >= 1 && Q >= 0 && C >= 1 && C <= 32 && n_node + Q < (int64_t(1) << 31),
               "tuple_layer: needs mode 1 | 2, n_node >= 1, 1 <= C <= 32");
-  LPG_REQUIRE(x && cnt && w_a && w_r && b_a && b_r && part && (Q == 0 || (qinfo && y_q)), "tuple_layer: null pointer");
-  LPG_REQUIRE(n_blocks >= 1 && n_blocks <= kTwMaxBlocks, "tuple_layer: 1 <= n_blocks <= %d", kTwMaxBlocks);
+  LPG_REQUIRE(x && ax && cnt && w_a && w_r && b_a && b_r && part && (Q == 0 || (qinfo && y_q)), "tuple_layer: null pointer");
+  LPG_REQUIRE(n_blocks == tw_blocks(n_node, Q), "tuple_layer: n_blocks must be lpg_tuple_layer_blocks(n_node, Q)");
   LPG_REQUIRE(reinterpret_cast<uintptr_t>(qinfo) % 16 == 0, "tuple_layer: qinfo must be 16-byte aligned");
-  const bool inl = ax == nullptr, defer = in_part != nullptr;
-  LPG_REQUIRE(!inl || (mode == 1 && rowptr && col), "tuple_layer: without A x the member adjacency is needed (mode 1 only)");
   LPG_REQUIRE(mode == 1 || (hq_prev || Q == 0), "tuple_layer: mode 2 needs the previous layer's non-member rows");
-  LPG_REQUIRE(!defer || (mode == 1 && in_rb >= 1 && in_rb <= 64 && in_n >= 1), "tuple_layer: bad deferred-norm arguments");
-  LPG_REQUIRE(ldx >= (mode == 1 ? C : 2 * C) && (inl || ldax >= (mode == 1 ? C : 2 * C)), "tuple_layer: row strides too small");
+  LPG_REQUIRE(ldx >= (mode == 1 ? C : 2 * C) && ldax >= (mode == 1 ? C : 2 * C), "tuple_layer: row strides too small");
+  LPG_REQUIRE(n_node * (ldx > ldax ? ldx : ldax) < (int64_t(1) << 31) && (n_node + Q) * 2 * C < (int64_t(1) << 31),
+              "tuple_layer: operands of 2^31 elements or more (32-bit element offsets inside)");
   TwLayerArgs a{};
-  a.x = x; a.ax = ax; a.rowptr = rowptr; a.col = col; a.hq_prev = hq_prev; a.cnt = cnt; a.qinfo = qinfo;
+  a.x = x; a.ax = ax; a.hq_prev = hq_prev; a.cnt = cnt; a.qinfo = qinfo;
   a.w_a = w_a; a.w_r = w_r; a.b_a = b_a; a.b_r = b_r; a.t_node = t_node; a.y_q = y_q; a.part = part;
-  a.nin = TwNormIn{in_part, in_gw, in_gb, in_gms, static_cast<int>(in_rb), in_relu, static_cast<int>(in_n), in_eps};
   a.ldx = ldx; a.ldax = ldax; a.n_node = static_cast<int>(n_node); a.Q = static_cast<int>(Q); a.C = static_cast<int>(C);
+  a.tile = tw_tile(n_node, Q);
   const dim3 grid(static_cast<unsigned>(n_blocks)), block(kTwBlock);
   hipStream_t st = as_stream(stream);
-  if (mode == 2) hipLaunchKernelGGL((tw_layer_kernel<2, false, false>), grid, block, 0, st, a);
-  else if (inl && defer) hipLaunchKernelGGL((tw_layer_kernel<1, true, true>), grid, block, 0, st, a);
-  else if (inl) hipLaunchKernelGGL((tw_layer_kernel<1, true, false>), grid, block, 0, st, a);
-  else if (defer) hipLaunchKernelGGL((tw_layer_kernel<1, false, true>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((tw_layer_kernel<1, false, false>), grid, block, 0, st, a);
+  if (mode == 2) hipLaunchKernelGGL((tw_layer_kernel<2>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((tw_layer_kernel<1>), grid, block, 0, st, a);
   return check_launch("tuple_layer");
 }
 
 LPG_EXPORT int lpg_tuple_fold_f64(const double* part, int64_t n_in, double* out, int64_t n_out, void* stream) {
   LPG_REQUIRE(part && out && n_in >= 1 && n_out >= 1 && n_out <= kTwMaxPart, "tuple_fold: bad argument");
-  hipLaunchKernelGGL(tw_fold_kernel, dim3(static_cast<unsigned>(n_out)), dim3(128), 0, as_stream(stream), part,
+  hipLaunchKernelGGL(tw_fold_kernel, dim3(static_cast<unsigned>(n_out)), dim3(kBlock), 0, as_stream(stream), part,
                      static_cast<int>(n_in), out);
   return check_launch("tuple_fold");
 }

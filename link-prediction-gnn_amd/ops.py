@@ -688,7 +688,7 @@ def compact_cols(mat, keep):
 # ------------------------------------------------------------------------------ 2-WL layers without the tuple graph
 TUPLE_MAX_C = 32          # channels the tuple-layer kernels take (lanes 0-31 / 32-63 = the two orientations)
 TUPLE_MAX_PART = 64       # partial-sum blocks a consumer folds by itself
-TUPLE_INLINE_MAX_ROW = 512    # member rows up to this length are summed inside the layer kernel (no A x launch)
+TUPLE_AX_SMALL_MAX_ROW = 2048  # longest member row for which A x takes the workgroup-per-node kernel (small graphs)
 
 
 class TuplePlan:
@@ -742,39 +742,54 @@ def _norm_args(norm, relu):
     return [_ptr(w), _ptr(b), _ptr(ms), float(norm.eps), int(relu)]
 
 
+def tuple_ax_small(plan, x1):
+    """(x1n, A x1n) over a TuplePlan's member adjacency for graphs with short member rows: a workgroup per node
+    (lpg_tuple_ax_small_f32).  x1: the 1-WL output [N, C], a tensor or a `Deferred` whose GraphNorm (+ ReLU) is applied
+    on load."""
+    dfr = x1 if isinstance(x1, Deferred) else None
+    y1 = _c(dfr.y if dfr is not None else x1, torch.float32)
+    _need_gpu(y1)
+    N, C = y1.shape
+    if N != plan.n_node or C > TUPLE_MAX_C:
+        raise ValueError("tuple_ax_small: x1 must be [n_node, C <= 32]")
+    if dfr is not None and dfr.part is not None:
+        nm = dfr.norm
+        gw, gb, gms = _c(nm.weight, torch.float32), _c(nm.bias, torch.float32), _c(nm.mean_scale, torch.float32)
+        din = [_ptr(dfr.part), _ptr(gw), _ptr(gb), _ptr(gms), dfr.part.shape[0], int(dfr.relu), float(nm.eps)]
+        _lib.keepalive(dfr.part, gw, gb, gms)
+    else:
+        din = [0, 0, 0, 0, 1, 0, 1e-5]
+    x1n, ax = torch.empty_like(y1), torch.empty_like(y1)
+    _lib.keepalive(y1, plan.A.rowptr, plan.A.col, x1n, ax)
+    _lib.call("lpg_tuple_ax_small_f32", N, C, _ptr(y1), y1.stride(0), _ptr(plan.A.rowptr), _ptr(plan.A.col), *din, _ptr(x1n),
+              _ptr(ax), _stream())
+    return x1n, ax
+
+
 def tuple_layer(plan, mode, x, ax, w_a, w_r, b_a, b_r, hq_prev=None, want_t=True):
-    """one 2-WL layer over a TuplePlan (lpg_tuple_layer_f32).  mode 1: x = the 1-WL output [N, C] (a tensor or a
-    `Deferred`), ax = A x or None (summed inside); mode 2: x = (F_a | F_r) [N, 2C], ax = A x, hq_prev [Q, C].
+    """one 2-WL layer over a TuplePlan (lpg_tuple_layer_f32).  mode 1: x = the 1-WL output [N, C], ax = A x;
+    mode 2: x = (F_a | F_r) [N, 2C], ax = A x, hq_prev [Q, C].
     -> (t_node [N, 2C] or None, y_q [Q, 2C], part [n_blocks, 2, 64])"""
     lib = _lib.load()
-    dfr = x if isinstance(x, Deferred) else None
-    xt = _c(dfr.y if dfr is not None else x, torch.float32)
-    ax = _c(ax, torch.float32)
+    xt, ax = _c(x, torch.float32), _c(ax, torch.float32)
     w_a, w_r, b_a, b_r = (_c(v, torch.float32) for v in (w_a, w_r, b_a, b_r))
     _need_gpu(xt, ax, w_a, w_r, b_a, b_r, hq_prev)
     C = w_a.shape[0]
     N, Q = plan.n_node, plan.Q
     if w_a.shape != (C, C) or w_r.shape != (C, C) or C > TUPLE_MAX_C or xt.shape != (N, C if mode == 1 else 2 * C):
         raise ValueError("tuple_layer: shapes do not match (square [C, C] weights, C <= 32, x [N, C] / [N, 2C])")
-    if ax is not None and ax.shape != xt.shape:
+    if ax.shape != xt.shape:
         raise ValueError("tuple_layer: A x must have x's shape")
     dev = xt.device
     nb = int(_lib.check(lib.lpg_tuple_layer_blocks(N, Q), "tuple_layer_blocks"))
     t_node = torch.empty((N, 2 * C), dtype=torch.float32, device=dev) if want_t else None
     y_q = torch.empty((max(Q, 1), 2 * C), dtype=torch.float32, device=dev)
     part = torch.empty((nb, 2, 64), dtype=torch.float64, device=dev)
-    if dfr is not None and dfr.part is not None:
-        nm = dfr.norm
-        gw, gb, gms = _c(nm.weight, torch.float32), _c(nm.bias, torch.float32), _c(nm.mean_scale, torch.float32)
-        din = [_ptr(dfr.part), _ptr(gw), _ptr(gb), _ptr(gms), dfr.part.shape[0], int(dfr.relu), N, float(nm.eps)]
-        _lib.keepalive(dfr.part, gw, gb, gms)
-    else:
-        din = [0, 0, 0, 0, 1, 0, 1, 1e-5]
     hq_prev = _c(hq_prev, torch.float32)
-    _lib.keepalive(xt, ax, plan.A.rowptr, plan.A.col, hq_prev, plan.cnt, plan.qinfo, w_a, w_r, b_a, b_r, t_node, y_q, part)
-    _lib.call("lpg_tuple_layer_f32", int(mode), N, Q, C, _ptr(xt), xt.stride(0), _ptr(ax), 0 if ax is None else ax.stride(0),
-              _ptr(plan.A.rowptr), _ptr(plan.A.col), _ptr(hq_prev), _ptr(plan.cnt), _ptr(plan.qinfo), _ptr(w_a), _ptr(w_r),
-              _ptr(b_a), _ptr(b_r), _ptr(t_node), _ptr(y_q), _ptr(part), nb, *din, _stream())
+    _lib.keepalive(xt, ax, hq_prev, plan.cnt, plan.qinfo, w_a, w_r, b_a, b_r, t_node, y_q, part)
+    _lib.call("lpg_tuple_layer_f32", int(mode), N, Q, C, _ptr(xt), xt.stride(0), _ptr(ax), ax.stride(0), _ptr(hq_prev),
+              _ptr(plan.cnt), _ptr(plan.qinfo), _ptr(w_a), _ptr(w_r), _ptr(b_a), _ptr(b_r), _ptr(t_node), _ptr(y_q),
+              _ptr(part), nb, _stream())
     if nb > TUPLE_MAX_PART:                    # big graphs: one more small launch folds the partial sums
         folded = torch.empty((16, 2, 64), dtype=torch.float64, device=dev)
         _lib.check(lib.lpg_tuple_fold_f64(_ptr(part), nb, _ptr(folded), 16, _stream()), "tuple_fold")

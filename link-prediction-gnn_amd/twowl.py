@@ -290,16 +290,17 @@ class LocalWLNet(nn.Module):
         return seen[k]
 
     def _tuple_recordable(self, tg):
-        """the per-node 2-WL stage is two launches (layer with the member rows summed inside + readout) that the
-        recorded argument block can hold"""
+        """the per-node 2-WL stage is three launches (A x per node, layer, readout) that the recorded argument block
+        can hold"""
         tp = tg.plan()
-        return (len(self.conv2s) == 1 and 0 <= tp.A.max_row <= _ops.TUPLE_INLINE_MAX_ROW
+        return (len(self.conv2s) == 1 and 0 <= tp.A.max_row <= _ops.TUPLE_AX_SMALL_MAX_ROW
                 and _lib.load().lpg_tuple_layer_blocks(tp.n_node, tp.Q) <= _ops.TUPLE_MAX_PART)
 
     def _two_wl_node(self, x1, tg, idx):
         """model.py:75-83 without the tuple graph: x1 = the 1-WL output [N, C] (tensor or `Deferred`).  Per 2-WL layer:
-        (A x) over the member adjacency -- inside the layer kernel when its rows are short --, one launch for both
-        orientations' node tables and non-member rows, GraphNorm folded into whichever kernel reads the result."""
+        (A x) over the member adjacency (a workgroup per node on the small-graph path, the CSR SpMM otherwise), one
+        launch for both orientations' node tables and non-member rows, GraphNorm folded into whichever kernel reads
+        the result."""
         tp = tg.plan()
         t = yq = part = prev = None
         for l, (seq_a, seq_r) in enumerate(zip(self.conv2s, self.conv2s_r)):
@@ -310,8 +311,8 @@ class LocalWLNet(nn.Module):
             ba, br = (ca.bias if ca.bias is not None else zeros), (cr.bias if cr.bias is not None else zeros)
             cur = (seq_a.modlist[1], isinstance(seq_a.modlist[3], nn.ReLU), seq_r.modlist[1], isinstance(seq_r.modlist[3], nn.ReLU), ba, br)
             if l == 0:
-                if 0 <= tp.A.max_row <= _ops.TUPLE_INLINE_MAX_ROW:
-                    ax = None
+                if isinstance(x1, _ops.Deferred) and 0 <= tp.A.max_row <= _ops.TUPLE_AX_SMALL_MAX_ROW:
+                    x1, ax = _ops.tuple_ax_small(tp, x1)        # conv1's GraphNorm + ReLU applied on load
                 else:
                     if isinstance(x1, _ops.Deferred):
                         x1 = x1.norm(x1.y, relu=x1.relu) if x1.part is not None else x1.y
@@ -374,7 +375,7 @@ class LocalWLNet(nn.Module):
             hT = _ops.small_linear_t(h, seq.modlist[0].lin.weight)
             h, = _ops.small_gcn(N, [_side(hT, g1, seq)])
         if tg is not None:
-            return self._two_wl_node(h, tg, idx)        # conv1's GraphNorm + ReLU is applied by the layer kernel on load
+            return self._two_wl_node(h, tg, idx)        # conv1's GraphNorm + ReLU is applied where A x is made
         a = r = None
         for i, (seq_a, seq_r) in enumerate(zip(self.conv2s, self.conv2s_r)):
             wa, wr = seq_a.modlist[0].lin.weight, seq_r.modlist[0].lin.weight
