@@ -236,9 +236,7 @@ def twowl_scaled_bench(device, iters=20, n_pairs=100_000):
                 fwd = lambda: mod(x_deg, pos_edge, tg.pos1, idx, tg, True)
                 ref = fwd()
                 ms = _time_ms(fwd, iters)
-                x1 = mod._input_features(x_deg)
-                for conv1 in mod.conv1s:
-                    x1 = conv1(x1, pos_edge)
+                x1 = mod._one_wl_stage(x_deg, pos_edge)
                 if mode == "node":
                     stage = lambda: mod._two_wl_node(x1, tg, idx)
                 else:

@@ -192,6 +192,14 @@ int lpg_graphnorm_f32(const float* x, int64_t n, int64_t d, const float* weight,
                       const float* bias, const float* mean_scale, float eps, int relu,
                       const float* add_to, float* y, void* workspace, int64_t workspace_bytes,
                       void* stream);
+/* The same normalisation of a TABLE whose row v stands for row_weight[v] identical rows of the real input (n_total =
+ * their sum): statistics are the weighted column sums, only the n distinct rows are normalised.  LocalWLNet's first
+ * layer input GraphNorm(Embedding(deg)) [TwoWL/model/model.py:53-55,71] has one distinct row per distinct degree;
+ * row_weight = the degree histogram (lpg_degree_i64 of the index vector). */
+int lpg_graphnorm_weighted_f32(const float* x, int64_t n, int64_t d, const int64_t* row_weight,
+                               int64_t n_total, const float* weight, const float* bias,
+                               const float* mean_scale, float eps, int relu, float* y,
+                               void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- TwoWL pair ops (K7-K9)
  * embedding: out[i,:] = table[idx[i],:]                                  [model.py:71]

@@ -57,6 +57,11 @@ inline int chunk_for(int64_t e_cap) {
   // HBM-bound graphs end at 512 (|E| = 100 M: 8.55 ms vs 8.67 at 256, 8.89 at 128), a batch of SEAL
   // subgraphs (8.5 M edges, d = 32 and d = 1) at 64 (4-layer stack 2.35 ms at 512 -> 1.6 ms)
   while (c < kDefaultChunk && static_cast<int64_t>(c) * (int64_t(1) << 18) <= e_cap) c *= 2;
+  // mid-size graphs (round 3, profiles/spmm_mid_graph.py: |V| = 236 K, 2.8 M edges, d = 32): at 16-edge chunks nearly every
+  // chunk border cuts a row and the fix-up kernel costs as much as the main one -- 93 us at 16, 78 at 32, 70 at 64,
+  // 62 at 128, 84 at 256; the 8.5 M-edge SEAL batch was already best at 64
+  if (e_cap >= (int64_t(1) << 21) && c < 64) c = 64;
+  else if (e_cap >= (int64_t(1) << 19) && c < 32) c = 32;
   return c;
 }
 

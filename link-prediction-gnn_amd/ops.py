@@ -417,6 +417,27 @@ def graph_norm(x, weight, bias, mean_scale, eps=1e-5, relu=False, add_to=None, o
     return out
 
 
+def graph_norm_weighted(x, row_weight, n_total, weight, bias, mean_scale, eps=1e-5, relu=False):
+    """GraphNorm of a [V, d] table whose row v stands for row_weight[v] (int64) identical rows of the real input,
+    n_total rows in all (lpg_graphnorm_weighted_f32)."""
+    lib = _lib.load()
+    _need_gpu(x, row_weight, weight, bias, mean_scale)
+    x = _c(x, torch.float32)
+    row_weight = _c(row_weight, torch.int64)
+    n, d = x.shape
+    nbytes = _lib.check(lib.lpg_graphnorm_bytes(n, d), "graphnorm_bytes")
+    key = (x.device, _stream())
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _gn_ws[key] = ws
+    out = torch.empty_like(x)
+    _lib.check(lib.lpg_graphnorm_weighted_f32(_ptr(x), n, d, _ptr(row_weight), int(n_total), _ptr(_c(weight, torch.float32)),
+                                              _ptr(_c(bias, torch.float32)), _ptr(_c(mean_scale, torch.float32)), float(eps),
+                                              int(relu), _ptr(out), _ptr(ws), ws.numel(), _stream()), "graphnorm_weighted")
+    return out
+
+
 # ------------------------------------------------------------------------------ pair ops
 def embedding(table, idx):
     lib = _lib.load()

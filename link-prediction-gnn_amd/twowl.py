@@ -116,6 +116,7 @@ def tuple_graph(n_node: int, pos_edge, pred_edge):
     return TupleGraph(n_node, pos_edge, pred_edge)
 
 
+_TABLE_CONV1 = True            # kernel-per-op path: GraphNorm + conv1's linear on the embedding TABLE rows (see _one_wl_stage)
 _IMPLICIT_MODE = "node"        # "node": per-node sums all the way (csrc/tuple_wl.hip); "operator": GCNConv per orientation
 _side_streams = {}
 _PARALLEL_BRANCHES = os.environ.get("LPG_TWOWL_PARALLEL", "1") != "0"
@@ -256,9 +257,7 @@ class LocalWLNet(nn.Module):
             self._plan = _SmallPlan(key, rec["words"], rec["keep"] + [x, edge1, pos, idx, ei2, edge2, edge2_r],
                                     tuple(out.shape), out.device)
             return out
-        x = self._input_features(x)
-        for conv1 in self.conv1s:
-            x = conv1(x, edge1)                                        # K5 + K3/K4 + K6
+        x = self._one_wl_stage(x, edge1)
         if node_mode:
             return self._two_wl_node(x, tg, idx)                       # a6 + a7 + a8 on per-node sums
         x = _ops.pair_gather_mul(x, pos)                               # K7
@@ -326,6 +325,29 @@ class LocalWLNet(nn.Module):
         out = _ops.tuple_readout(tp, t, yq, part, *prev, idx, self.pred.weight, self.pred.bias)
         _ops.maybe_check(out.device, "LocalWLNet index")
         return out
+
+    def _one_wl_stage(self, x, edge1):
+        """model.py:71-73 on the kernel-per-op path.  Without node features the first layer's input GraphNorm(Embedding(deg))
+        has one distinct row per distinct degree: with far fewer table rows than nodes, the norm (statistics weighted by
+        the degree histogram) and conv1's linear run on the TABLE rows and the node rows are gathered from the product
+        -- [V, C1] instead of [N, C1] through three memory-bound passes (_TABLE_CONV1 = False keeps those)."""
+        convs = list(self.conv1s)
+        if (_TABLE_CONV1 and not self.use_node_feat and convs and _is_relu_conv(convs[0]) and x.is_cuda
+                and not isinstance(edge1, _ops.CSRGraph) and x.numel() >= 4 * self.emb[0].weight.shape[0]):
+            table, nm, seq = self.emb[0].weight, self.emb[1], convs.pop(0)
+            n = x.numel()
+            hist = _index_histogram(x, table.shape[0])                                 # index range checked here; memoised
+            tn = _ops.graph_norm_weighted(table, hist, n, nm.weight, nm.bias, nm.mean_scale, nm.eps)
+            hv = _ops.linear(tn, seq.modlist[0].lin.weight)                            # [V, C_out]
+            h = _ops.embedding(hv, x)
+            g1 = graph_cache.get(edge1, None, n, True)
+            y = g1.spmm(h, bias=seq.modlist[0].bias)
+            x = seq.modlist[1](y, relu=isinstance(seq.modlist[3], nn.ReLU))
+        else:
+            x = self._input_features(x)
+        for conv1 in convs:
+            x = conv1(x, edge1)                                        # K5 + K3/K4 + K6
+        return x
 
     def _input_features(self, x):
         """model.py:71: lin1(node_feat) (Linear + bias on the matrix cores, then the row-wise LayerNorm; the dropouts
@@ -436,6 +458,22 @@ class LocalWLNet(nn.Module):
                 p[f"{name}.{l}.act"] = isinstance(act, nn.ReLU)
         p["pred.weight"], p["pred.bias"] = t(self.pred.weight), t(self.pred.bias)
         return p
+
+
+_hist_cache = {}
+
+
+def _index_histogram(x, n_bins):
+    """int64 histogram of an index vector, memoised on the tensor's identity (a scoring loop passes the same degree vector
+    every time; most nodes share a handful of small degrees, so the count is hundreds of thousands of atomics on a few
+    addresses: 100 us for 236 K nodes)."""
+    key = (x.data_ptr(), x._version, x.numel(), x.device, n_bins)
+    hit = _hist_cache.get(key)
+    if hit is None:
+        if len(_hist_cache) >= 8:
+            _hist_cache.clear()
+        hit = _hist_cache[key] = (_ops.degree(x.reshape(-1), n_bins), x)        # holds x: its storage cannot be recycled
+    return hit[0]
 
 
 class CapturedForward:

@@ -2404,3 +2404,52 @@ def test_localwl_implicit_large_graph(dev, monkeypatch):
     err = np.abs(_np(got).astype(np.float64) - want).max() / np.abs(want).max()
     print(f"implicit TwoWL on |V| = {N}, {pe.shape[1]} graph tuples: max |logit error| {err:.1e} of the logit scale")
     assert err <= TOL
+
+
+def test_graph_norm_weighted_table_and_conv1_on_table_rows(dev, tw, monkeypatch):
+    """lpg_graphnorm_weighted_f32: GraphNorm of a table whose row v stands for hist[v] identical rows == GraphNorm of the
+    expanded [N, d] input restricted to the distinct rows (fp64 definition, 1e-5 of what it sums); and the 1-WL stage
+    that uses it (GraphNorm + conv1's linear on the embedding TABLE rows, twowl._one_wl_stage) == the row-by-row stage
+    == the fp64 oracle, on fb-pages-food and on a graph with 20 K nodes."""
+    from lpgnn_amd import ops, twowl
+    from oracle import aggregation as agg, twowl_int
+    rng = np.random.default_rng(8)
+    for V, d, N in [(111, 256, 620), (3000, 24, 50_000), (5, 7, 40)]:
+        table = (rng.standard_normal((V, d)) * rng.uniform(0.2, 3.0, size=(1, d)) + rng.uniform(-1, 1, size=(1, d))).astype(np.float32)
+        idx = rng.integers(0, V, size=N)
+        hist = np.bincount(idx, minlength=V).astype(np.int64)
+        w, b, ms = (rng.uniform(0.5, 1.5, d).astype(np.float32) for _ in range(3))
+        got = _np(ops.graph_norm_weighted(*(torch.from_numpy(a).to(dev) for a in (table, hist)), N,
+                                          *(torch.from_numpy(a).to(dev) for a in (w, b, ms))))
+        x64 = table.astype(np.float64)[idx]
+        want = agg.graph_norm(x64, w, b, ms)
+        mag = agg.graph_norm_mag(x64, w, b, ms)
+        present = hist > 0
+        first = np.array([np.nonzero(idx == v)[0][0] for v in np.nonzero(present)[0]])
+        assert np.all(np.abs(got[present] - want[first]) <= TOL * mag[first] + 1e-30)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    monkeypatch.setattr(twowl, "_SMALL_PATH", False)
+    cases = []
+    mod, x_deg, ei, pred, ei2, pos1 = _localwl_case(tw, 64, 24, 2, 1, dev)
+    cases.append((mod, x_deg, ei))
+    N, E = 20_000, 120_000
+    pe = twowl_int.double(rng.integers(0, N, size=(2, E)))
+    deg = np.bincount(pe[0], minlength=N).astype(np.int64)
+    torch.manual_seed(2)
+    cases.append((twowl.LocalWLNet(int(deg.max()), channels_1wl=32, channels_2wl=16).to(dev).eval(), deg, pe))
+    for mod, x_deg, ei in cases:
+        p = mod.export_params()
+        x = agg.input_features(p, x_deg)
+        for l in range(p["depth1"]):
+            x = agg.gcn_conv(x, ei, p[f"conv1s.{l}.lin.weight"], p[f"conv1s.{l}.bias"])
+            x = agg.graph_norm(x, p[f"conv1s.{l}.norm.weight"], p[f"conv1s.{l}.norm.bias"], p[f"conv1s.{l}.norm.mean_scale"])
+            if p[f"conv1s.{l}.act"]:
+                x = np.maximum(x, 0.0)
+        outs = []
+        for flag in (True, False):
+            monkeypatch.setattr(twowl, "_TABLE_CONV1", flag)
+            with torch.no_grad():
+                outs.append(_np(mod._one_wl_stage(t(x_deg), t(ei))).astype(np.float64))
+        scale = np.abs(x).max()
+        for o in outs:
+            assert np.abs(o - x).max() <= 2 * TOL * scale, np.abs(o - x).max() / scale
