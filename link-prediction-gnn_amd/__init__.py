@@ -10,4 +10,4 @@ from . import ops, torch_scatter, torch_sparse, nn, twowl, dist   # noqa: F401
 from .ops import CSRGraph                            # noqa: F401
 
 __all__ = ["ops", "torch_scatter", "torch_sparse", "nn", "twowl", "CSRGraph", "load_library", "LpgError"]
-from . import seal, data                             # noqa: F401,E402
+from . import seal, data, metrics                    # noqa: F401,E402

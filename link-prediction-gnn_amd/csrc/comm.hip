@@ -28,14 +28,14 @@ struct Rccl {
   bool ok = false;
 };
 
-Rccl& rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+char g_dl_error[256] = "no loader error";
+
+Rccl load_rccl() {
+  Rccl r;
   for (const char* name : {"librccl.so.1", "librccl.so"}) {
     r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (r.handle) break;
+    if (const char* e = dlerror()) snprintf(g_dl_error, sizeof(g_dl_error), "%s", e);     // dlerror() clears itself: read once
   }
   if (!r.handle) return r;
   auto sym = [&](const char* s) { return dlsym(r.handle, s); };
@@ -49,9 +49,14 @@ Rccl& rccl() {
   return r;
 }
 
+Rccl& rccl() {
+  static Rccl r = load_rccl();        // function-local static: initialised once, thread-safe (C++11)
+  return r;
+}
+
 int need_rccl() {
   if (rccl().ok) return LPG_OK;
-  set_error("RCCL is not available: dlopen(librccl.so.1) failed or a symbol is missing (%s)", dlerror() ? dlerror() : "no loader error");
+  set_error("RCCL is not available: dlopen(librccl.so.1) failed or a symbol is missing (%s)", g_dl_error);
   return LPG_E_UNSUPPORTED;
 }
 

@@ -128,7 +128,9 @@ PartWs carve_part(void* ws, int64_t E, int64_t N) {
 }
 
 inline bool use_partition(int64_t E, int64_t N) {
-  return (N >> kLowBits) + 1 <= kMaxBuckets && E >= 2 * N;
+  // strictly fewer buckets than threads: thread t = nb writes the chunk's end offset tab[.., nb], so nb must be <= 1023
+  // (with nb == 1024 that entry stayed uninitialised and N in [33 521 664, 33 554 431] counted bucket 1023 wrongly)
+  return (N >> kLowBits) + 1 < kMaxBuckets && E >= 2 * N;
 }
 
 // counting sort of one 16 K-index chunk by bucket, in LDS; the int64 indices are read once, 2 bytes per key leave

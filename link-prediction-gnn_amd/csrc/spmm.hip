@@ -68,9 +68,10 @@ inline int chunk_for(int64_t e_cap) {
 // Per-phase timing of one SpMM call (option spmm_phase_timing = 1; bench.py's per-kernel split of the step): four
 // library-owned events recorded on the launch stream around {main kernel | fix-up | empty rows}.  Results are not
 // affected; the records cost a few microseconds, so the option is off outside the measuring loop.
-hipEvent_t g_phase_ev[4];
-bool g_phase_ev_ready = false;
-bool g_phase_recorded = false;
+// (thread-local like SideStream: two host threads timing their own calls do not share events)
+thread_local hipEvent_t g_phase_ev[4];
+thread_local bool g_phase_ev_ready = false;
+thread_local bool g_phase_recorded = false;
 inline void phase_mark(int i, hipStream_t st) {
   if (!options().spmm_phase_timing) return;
   if (!g_phase_ev_ready) {
@@ -833,7 +834,11 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
   if (e_cap > 0 && narrow) {
     const int64_t n_chunks = ceil_div(e_cap, a.chunk);
     const int64_t gx = ceil_div(n_chunks, kBlock / kWave);
-    LPG_REQUIRE(gx < (int64_t(1) << 31), "csr_spmm: grid too large");
+    if (gx >= (int64_t(1) << 31)) {
+      if (side) (void)hipStreamWaitEvent(st, side->join, 0);      // never return while the hidden stream still writes y
+      set_error("csr_spmm: grid too large");
+      return LPG_E_INVALID;
+    }
     constexpr int PV = 16 / sizeof(T);
     const bool vio = d % PV == 0 && ldx % PV == 0 && ldy % PV == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(y) % 16 == 0;
@@ -859,7 +864,10 @@ int spmm_entry(const void* plan, const int64_t* rowptr, const int32_t* col, cons
     const bool wide = d % WIDE == 0 && ldx % WIDE == 0 && ldy % WIDE == 0 &&
                       reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
     const int rc = wide ? launch_vec<T, WIDE>(a, e_cap, st) : launch_vec<T, 1>(a, e_cap, st);
-    if (rc != LPG_OK) return rc;
+    if (rc != LPG_OK) {
+      if (side) (void)hipStreamWaitEvent(st, side->join, 0);      // the caller's stream owns y again before the error returns
+      return rc;
+    }
   }
   phase_mark(2, st);
   if (n_empty_hint == 0) {

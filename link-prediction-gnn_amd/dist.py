@@ -425,8 +425,15 @@ class RcclComm:
     def reduce_scatter(self, send, out=None):
         """send [world * k, ...] -> this rank's block of the sum, [k, ...]"""
         bf, st = self._args(send)
+        if send.shape[0] % self.world:
+            raise ValueError(f"reduce_scatter: {send.shape[0]} rows do not split over {self.world} ranks")
         k = send.shape[0] // self.world
-        out = out if out is not None else torch.empty((k,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if out is None:
+            out = torch.empty((k,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        elif (out.numel() * self.world != send.numel() or out.dtype != send.dtype or out.device != send.device
+              or not out.is_contiguous()):
+            raise ValueError("reduce_scatter: `out` must be a contiguous tensor of this rank's block "
+                             f"({k} x {tuple(send.shape[1:])}, {send.dtype}) on the same device")
         self._lib.check(self._lib.load().lpg_reduce_scatter_sum(self._comm, send.data_ptr(), out.data_ptr(), out.numel(), bf, st),
                         "reduce_scatter_sum")
         return out

@@ -257,22 +257,7 @@ def _host_capped_nodes(pair, rowptr, col, max_neighbors, rng):     # (rowptr / c
     return [u, v] + sorted(sub)
 
 
-def _rank_auc(y, s):
-    """ROC AUC with average ranks for ties (== sklearn.metrics.roc_auc_score)."""
-    s = s.double()
-    order = torch.argsort(s, stable=True)
-    ss = s[order]
-    first = torch.ones_like(ss, dtype=torch.bool)
-    first[1:] = ss[1:] != ss[:-1]
-    grp = torch.cumsum(first, 0) - 1
-    cnt = torch.bincount(grp)
-    start = torch.cumsum(cnt, 0) - cnt
-    avg = (start.double() + (cnt.double() - 1) / 2 + 1)[grp]
-    ranks = torch.empty_like(avg)
-    ranks[order] = avg
-    y = y.bool()
-    npos, nneg = int(y.sum()), int((~y).sum())
-    return float((ranks[y].sum() - npos * (npos + 1) / 2) / (npos * nneg))
+from .metrics import rank_auc as _rank_auc  # noqa: E402  (public: lpgnn_amd.metrics.rank_auc)
 
 
 def auto_hop(positive, negative, graph, test_ratio=0.1):
@@ -359,16 +344,34 @@ def _cpython_set_order(tag_lists):
     return list(s)
 
 
+def _distinct_in_first_occurrence_order(tags_h, n_h):
+    """per subgraph, its distinct tags in the order they first appear -- all set(tags) depends on (duplicates do not change
+    a set) -- for the whole [B, 128] batch at once: one np.unique over (row, tag) keys instead of a Python pass over every
+    vertex.  -> list of B short Python lists."""
+    B, W = tags_h.shape
+    valid = np.arange(W)[None, :] < n_h[:, None]
+    rows, cols = np.nonzero(valid)
+    key = rows.astype(np.int64) * (_TAG_BOUND + 2) + tags_h[rows, cols].astype(np.int64)
+    uniq, first = np.unique(key, return_index=True)              # first = first flat position (row-major: vertex order)
+    order = np.lexsort((cols[first], uniq // (_TAG_BOUND + 2)))
+    r, t = (uniq // (_TAG_BOUND + 2))[order], (uniq % (_TAG_BOUND + 2))[order]
+    cuts = np.searchsorted(r, np.arange(1, B))
+    return [part.tolist() for part in np.split(t, cuts)]
+
+
 def compact_tag_map(batch):
     """Global tag compaction (SEAL/config/subgraph.py:84-101): (tag_map int32 [TAG_BOUND + 1], T) with
     tag_map[raw tag] = compacted tag, -1 for absent tags.  The reference maps a tag to its position in
     list(set(all tags)), i.e. CPython set iteration order.  For non-negative ints below 8 that order is ascending
-    whatever the history of the set (hash(i) = i, >= 8 slots, no collision can happen), and hop <= 1 subgraphs
-    -- all the reference can run -- only produce DRNL tags {0, 1, 2, 3, 4, 6}: every vertex is adjacent to a
-    target, so its distance to the other one is <= 4 or infinite.  That case is one device launch (ascending rank
-    of the presence table).  When a larger tag is present (replayed node lists, hand-built batches) collisions in
-    the set's hash table can reorder it, and the map is rebuilt on the host by running the reference's own set
-    operations over the batch's tag lists -- same order as oracle.seal_int.compact_tags by construction."""
+    whatever the history of the set (hash(i) = i, >= 8 slots, no collision can happen), and UNDIRECTED hop <= 1
+    subgraphs only produce DRNL tags {0, 1, 2, 3, 4, 6}: every vertex is adjacent to a target, so its distance to the
+    other one is <= 4 or infinite.  That case is one device launch (ascending rank of the presence table).
+    Directed graphs (network_type = 1: a vertex reached from one target may be many hops from the other), hop 2 or
+    replayed / hand-built batches do produce tags >= 8; then collisions in the set's hash table can reorder it, and
+    the map is rebuilt on the host by running the reference's own set operations over the batch's per-subgraph tag
+    sets -- same order as oracle.seal_int.compact_tags by construction.  That branch copies the [B, 128] tags to the
+    host and takes ~0.3 s per 100 K subgraphs (a vectorised distinct-tags pass + one Python set union per subgraph):
+    the "no host sync per forward" property of score_links / score_stack holds for the tag-< 8 case only."""
     dev = batch.tags.device
     if batch.tag_present is not None:                        # filled by the extraction kernel as it wrote the tags:
         tag_map, T = batch.tag_map()                         # ranked with the batch's offsets, one launch, one host read
@@ -386,7 +389,7 @@ def compact_tag_map(batch):
     if max_tag < _SET_MIN_SLOTS or T == 0:
         return tag_map, T
     tags_h, n_h = batch.tags.cpu().numpy(), batch.n.cpu().numpy()
-    order = _cpython_set_order(tags_h[b, : n_h[b]] for b in range(tags_h.shape[0]))
+    order = _cpython_set_order(_distinct_in_first_occurrence_order(tags_h, n_h))
     if order == sorted(order) or set(order) == set(range(len(order))):
         # ascending already -- or the reference's "already contiguous" branch (:98), which leaves the tags alone
         return tag_map, T

@@ -2,7 +2,7 @@
 
     degree / reverse / double / get_ei2 / sample_block     <-> TwoWL/utils.py:8-90
     Seq / LocalWLNet                                        <-> TwoWL/model/model.py:8-96
-    test_forward                                            <-> TwoWL/model/train.py:50-60
+    test_forward / test                                     <-> TwoWL/model/train.py:50-68
 
 Every tensor op below is a kernel of liblpg_hip.so.  state_dict keys equal the reference's, so
 weights trained with the reference load unchanged.  Eval-mode forward only.
@@ -166,9 +166,11 @@ class _SmallPlan:
 
 
 def _tkey(t):
+    """identity of a tensor as the recorded launch block sees it: storage address, version, full shape and strides (a
+    view with the same first address but other strides is another input)"""
     if isinstance(t, TupleGraph):
         return (id(t), _tkey(t.pos_edge), _tkey(t.pred_edge), None if t.blocked_idx is None else _tkey(t.blocked_idx))
-    return (t.data_ptr(), t._version, t.shape[0])
+    return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
 
 
 class LocalWLNet(nn.Module):
@@ -201,6 +203,12 @@ class LocalWLNet(nn.Module):
         self.conv2s_r = nn.ModuleList([relu_conv(channels_2wl, channels_2wl, dp_2wl, True) for _ in range(depth2)])
         self.pred = nn.Linear(channels_2wl, 1)
 
+    def _plan_key(self, x, edge1, pos, idx, ei2):
+        """what a recorded launch block is valid for: the input tensors, every parameter's STORAGE and version (p.data =
+        other_tensor keeps the version but moves the storage) and the device the launches go to"""
+        return (_tkey(x), _tkey(edge1) if torch.is_tensor(edge1) else id(edge1), _tkey(pos), _tkey(idx), _tkey(ei2),
+                tuple([(p.data_ptr(), p._version) for p in self._plan_params]), torch.cuda.current_device())
+
     def _apply(self, fn, *args, **kwargs):
         self._plan = None                     # .to() / .float() replace the parameter tensors
         return super()._apply(fn, *args, **kwargs)
@@ -216,8 +224,7 @@ class LocalWLNet(nn.Module):
         if plan is not None and _SMALL_PATH and idx is not None and ei2 is not None:
             # steady state of a scoring loop (TwoWL/model/train.py:54-60 calls the same tensors every time): the whole
             # forward is one host call over the recorded argument block
-            key = (_tkey(x), _tkey(edge1) if torch.is_tensor(edge1) else id(edge1), _tkey(pos), _tkey(idx), _tkey(ei2),
-                   tuple([p._version for p in self._plan_params]))
+            key = self._plan_key(x, edge1, pos, idx, ei2)
             if key == plan.key:
                 out = torch.empty(plan.out_shape, dtype=torch.float32, device=plan.device)
                 plan.block[plan.out_word] = out.data_ptr()
@@ -248,13 +255,15 @@ class LocalWLNet(nn.Module):
             # first forward over these inputs: run the launches one by one, recording them (and checking the indices:
             # the recorded block is only replayed for the same tensors at the same versions, so once is enough)
             self._plan_params = [p for p in self.parameters()]
-            key = (_tkey(x), _tkey(edge1) if torch.is_tensor(edge1) else id(edge1), _tkey(pos), _tkey(idx), _tkey(ei2),
-                   tuple([p._version for p in self._plan_params]))
+            key = self._plan_key(x, edge1, pos, idx, ei2)
             if node_mode:
                 tg.plan()                          # built (and synchronised) outside the recording
             with _lib.recording() as rec:
                 out = self._forward_small(x, edge1, pos, idx, edge2, edge2_r, tg)
-            self._plan = _SmallPlan(key, rec["words"], rec["keep"] + [x, edge1, pos, idx, ei2, edge2, edge2_r],
+            # keep the parameters' STORAGE (p.data), not only the Parameter objects: a rebound p.data must not free what
+            # the block's raw pointers name
+            self._plan = _SmallPlan(key, rec["words"], rec["keep"] + [x, edge1, pos, idx, ei2, edge2, edge2_r]
+                                    + [p.data for p in self._plan_params],
                                     tuple(out.shape), out.device)
             return out
         x = self._one_wl_stage(x, edge1)
@@ -509,6 +518,20 @@ def test_forward(mod, x, ei, pos1, y_len, ei2):
     if idx is None:                                    # the index vector only depends on two sizes: built once
         idx = _idx_cache[key] = ei.shape[1] + torch.arange(y_len, device=x.device)
     return mod(x, ei, pos1, idx, ei2, True)
+
+
+@torch.no_grad()
+def test(mod, dataset, test=False):
+    """TwoWL/model/train.py:50-68 -- the scoring wrapper the reference times (records_auc/*twowl.txt 'Time'): the forward
+    over the split's candidates, sigmoid, ROC AUC and the ROC curve against the labels of the even (first-direction)
+    tuples.  `dataset`: the reference's own fields (x, ei, pos1, y, ei2; lpgnn_amd.data.dataset).  Everything stays on
+    the device; returns (auc: float, fpr, tpr: float64 tensors) like the reference's (result, fpr, tpr)."""
+    from . import metrics
+    pred = test_forward(mod, dataset.x, dataset.ei, dataset.pos1, dataset.y.shape[0], dataset.ei2)
+    sig = pred.sigmoid().reshape(-1)
+    labels = dataset.y.reshape(-1)[0::2]                        # :61-64: mask = [True, False, True, ...]
+    fpr, tpr, _ = metrics.roc_curve(labels, sig)
+    return metrics.rank_auc(labels, sig), fpr, tpr
 
 
 def get_ei2(n_node: int, pos_edge, pred_edge):

@@ -51,3 +51,21 @@ def test_seal_load_data_matches_reference(golden_dir):
     posd, negd, nd = data.seal_load_data(os.path.join(golden_dir, "fb-pages-food.edges"), network_type=1, seed=0)
     haved = set(map(tuple, posd.tolist()))
     assert nd == 620 and all(a != b and (a, b) not in haved for a, b in negd.tolist())
+
+
+def test_metrics_equal_sklearn_with_ties():
+    """lpgnn_amd.metrics.rank_auc / roc_curve (what twowl.test and seal.auto_hop use, TwoWL/model/train.py:66-67) against
+    sklearn.metrics on scores with many ties, few levels and tiny sizes."""
+    import numpy as np
+    import torch
+    from sklearn.metrics import roc_auc_score, roc_curve
+    from lpgnn_amd import metrics
+    rng = np.random.default_rng(0)
+    for n, levels in [(50, 5), (400, 1000), (7, 2), (1000, 13), (386, 3)]:
+        y = rng.integers(0, 2, n)
+        y[0], y[1] = 0, 1
+        s = rng.integers(0, levels, n) / levels
+        assert abs(metrics.rank_auc(torch.from_numpy(y), torch.from_numpy(s)) - roc_auc_score(y, s)) < 1e-12
+        f, t, th = metrics.roc_curve(torch.from_numpy(y), torch.from_numpy(s))
+        f0, t0, th0 = roc_curve(y, s)
+        assert np.allclose(f.numpy(), f0) and np.allclose(t.numpy(), t0) and np.allclose(th.numpy()[1:], th0[1:])

@@ -973,6 +973,19 @@ def test_seal_subgraphs_golden(dev, sl, golden_dir, hop, directed):
     if not capped.any():                                 # the product's own map of the same batch (no replayed pairs)
         tm, T = seal.compact_tag_map(batch)
         assert T == len(order) and all(int(_np(tm)[t]) == tmap[t] for t in order)
+    if directed:
+        # the directed run reaches tags >= 8 (round-2 advisor: every directed batch takes compact_tag_map's host branch):
+        # the product's map of the un-capped pairs' device batch against the oracle's set algebra over the same lists
+        assert max(int(tg.max()) for _, tg, _ in raw) >= 8
+        keep = np.nonzero(~capped)[0]
+        sub = seal.extract_subgraphs(pairs[keep], graph, hop, cap_policy="report")
+        lists = [tags[g, : n[g]].tolist() for g in keep]
+        want_tags, want_T = seal_int.compact_tags(lists)
+        tm, T = seal.compact_tag_map(sub)
+        assert T == want_T and sub._max_tag >= 8
+        tmh = _np(tm)
+        for raw_l, want_l in zip(lists[:400], want_tags[:400]):
+            assert [int(tmh[t]) for t in raw_l] == want_l
     for g in range(len(pairs)):
         nd, tg, bb = raw[g]
         ref_nd = nodes_ref[off[g]:off[g + 1]]
@@ -981,7 +994,7 @@ def test_seal_subgraphs_golden(dev, sl, golden_dir, hop, directed):
         got = dict(zip(nd[2:].tolist(), [tmap[int(t)] for t in tg[2:]]))
         assert got == want, g
         assert [tmap[int(t)] for t in tg[:2]] == tags_ref[off[g]:off[g] + 2].tolist()
-        if g % 7 == 0 or capped[g]:                 # adjacency: crc of the canonical-order bit matrix
+        if True:                                    # adjacency of EVERY pair: crc of the canonical-order bit matrix
             a = _unpack_adj(bb, len(nd))
             p = np.concatenate([[0, 1], np.argsort(np.asarray(nd[2:]), kind="stable") + 2])
             a = a[p][:, p]
@@ -1221,6 +1234,20 @@ def test_small_forward_plan_replay(dev, tw):
     bad[5, 0] = 10_000                                                    # the recording call still checks indices
     with pytest.raises(IndexError):
         twowl.test_forward(mod, xd, eit, bad, y_len, e2)
+    # a parameter whose STORAGE is swapped (p.data = ...) keeps its version: the key holds the address too (round-2 advisor)
+    base = twowl.test_forward(mod, xd, eit, p1, y_len, e2)
+    plan3 = mod._plan
+    assert torch.equal(twowl.test_forward(mod, xd, eit, p1, y_len, e2), base) and mod._plan is plan3
+    v0 = mod.pred.bias._version
+    mod.pred.bias.data = mod.pred.bias.data.clone() + 2.0
+    assert mod.pred.bias._version == v0
+    swapped = twowl.test_forward(mod, xd, eit, p1, y_len, e2)
+    assert mod._plan is not plan3 and torch.allclose(swapped, base + 2.0, atol=1e-6)
+    # a view with the same first address and row count but another row stride is another input
+    wide = torch.zeros((p1.shape[0], 4), dtype=torch.int64, device=dev)
+    wide[:, :2] = p1
+    viewed = twowl.test_forward(mod, xd, eit, wide[:, :2], y_len, e2)
+    assert torch.equal(viewed, swapped)
 
 
 def test_gcnconv_module_takes_small_graph_kernels(dev, tw, monkeypatch):
@@ -1648,6 +1675,21 @@ def test_data_path_to_forward_fb_pages_food(dev, golden_dir):
     mod = twowl.LocalWLNet(bg.max_x, channels_1wl=32, channels_2wl=16).to(dev).eval()
     out = twowl.test_forward(mod, x, ei, pos1, y.shape[0], ei2)
     assert out.shape == (y.shape[0] // 2, 1) and torch.isfinite(out).all()
+    # the scoring wrapper the reference times (TwoWL/model/train.py:50-68): forward -> sigmoid -> AUC / ROC on the device,
+    # against sklearn on the host; and the same split through the structured tuple graph (pattern "2wl_l_implicit")
+    from sklearn.metrics import roc_auc_score, roc_curve
+    auc, fpr, tpr = twowl.test(mod, data.dataset(*bg.split(2)))
+    lab, sig = _np(y).reshape(-1)[0::2], _np(out.sigmoid()).reshape(-1)
+    f0, t0, _ = roc_curve(lab, sig)
+    assert abs(auc - roc_auc_score(lab, sig)) < 1e-9 and np.allclose(_np(fpr), f0) and np.allclose(_np(tpr), t0)
+    torch.manual_seed(0)
+    bi = data.load_dataset(os.path.join(golden_dir, "fb-pages-food.edges"), pattern="2wl_l_implicit", device=dev)
+    bi.preprocess()
+    bi.setPosDegreeFeature()
+    assert isinstance(bi.ei2s[2], twowl.TupleGraph) and torch.equal(bi.pos1s[2], pos1)
+    auc_i, _, _ = twowl.test(mod, data.dataset(*bi.split(2)))
+    out_i = twowl.test_forward(mod, *[bi.split(2)[k] for k in (0, 2, 4)], y.shape[0], bi.ei2s[2])
+    assert (out_i - out).abs().max() <= 2e-5 * out.abs().max() and abs(auc_i - auc) < 2e-3
 
 
 def test_trained_model_auc_parity_fb_pages_food(dev, golden_dir):
@@ -2453,3 +2495,21 @@ def test_graph_norm_weighted_table_and_conv1_on_table_rows(dev, tw, monkeypatch)
         scale = np.abs(x).max()
         for o in outs:
             assert np.abs(o - x).max() <= 2 * TOL * scale, np.abs(o - x).max() / scale
+
+
+@pytest.mark.parametrize("n", [1022 * 32768 + 5, 1023 * 32768 + 5])
+def test_degree_partition_bucket_limit(dev, n, monkeypatch):
+    """the chunk-local partition of csrc/degree.hip holds one bucket per 32 K nodes and at most 1023 of them (thread t
+    writes bucket t's offset, thread nb the chunk total): n = 1022 * 32768 + 5 is the largest bucket count it takes,
+    n = 1023 * 32768 + 5 (1024 buckets: the round-2 advisor's case, where the last bucket's end offset stayed
+    uninitialised) must go to the full sort.  Both against the atomic kernels, E = 2 n, keys in the top bucket."""
+    from lpgnn_amd import ops
+    E = 2 * n
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(n % 1000)
+    idx = torch.randint(0, n, (E,), generator=gen, device=dev)
+    idx[: E // 50] = n - 1 - torch.randint(0, 40_000, (E // 50,), generator=gen, device=dev)     # the last two buckets
+    got = ops.degree(idx, n)
+    monkeypatch.setattr(ops, "DEGREE_SORT_MIN", 1 << 62)
+    want = ops.degree(idx, n)
+    assert int(want.sum()) == E and torch.equal(got, want)
