@@ -237,6 +237,62 @@ def extract_subgraphs(pairs, graph, hop, max_neighbors=100, replay_nodes=None, r
     return SubgraphBatch(pairs, nodes, n, tags, adj_bits, capped, present)
 
 
+def _insertion_order_neighbours(train_pos, wanted, directed):
+    """{node: its neighbour list in networkx's adjacency-dict order} for the nodes in `wanted`: G.add_edges_from(train_pos)
+    (SEAL/config/subgraph.py:69) appends b to adj[a] (and a to adj[b] for nx.Graph) the FIRST time the pair shows up,
+    so list(nx.neighbors(G, x)) is x's partners in order of first appearance over the rows.  train_pos: [P, 2] numpy."""
+    a, b = train_pos[:, 0].astype(np.int64), train_pos[:, 1].astype(np.int64)
+    if directed:
+        src, dst = a, b
+    else:                                          # row i contributes (a -> b) then (b -> a)
+        src = np.stack([a, b], 1).reshape(-1)
+        dst = np.stack([b, a], 1).reshape(-1)
+    pick = np.isin(src, np.fromiter(wanted, dtype=np.int64, count=len(wanted)))
+    src, dst = src[pick], dst[pick]
+    out = {int(x): [] for x in wanted}
+    seen = set()
+    for x, y in zip(src.tolist(), dst.tolist()):
+        if (x, y) not in seen:
+            seen.add((x, y))
+            out[x].append(y)
+    return out
+
+
+def host_cap_node_lists(pairs, flagged, train_pos, max_neighbors, seed, directed=False):
+    """The reference's node sets for the pairs its 100-node truncation can touch, SEED FOR SEED (SEAL/config/subgraph.py:
+    118-135 at hop = 1 under np.random.seed(seed)): every pair -- negatives first, then positives, the order link2subgraph
+    walks them in (:74-82) -- draws np.random.shuffle([u, v]) (:122); a pair whose running size reaches the cap at a
+    visit shuffles that node's neighbour list, taken in networkx insertion order, and keeps its head (:127-130).
+    `flagged`: the pairs the device reported as capped in EITHER visiting order (a superset of those that truncate in the
+    drawn order; only they can consume more of the stream).  Returns {pair index: [u, v] + sorted(other vertices)}."""
+    rng = np.random.RandomState(seed)
+    flagged = set(int(i) for i in flagged)
+    wanted = set()
+    for i in flagged:
+        wanted.update((int(pairs[i][0]), int(pairs[i][1])))
+    nbrs = _insertion_order_neighbours(np.asarray(train_pos), wanted, directed) if wanted else {}
+    out = {}
+    for i in range(len(pairs)):
+        u, v = int(pairs[i][0]), int(pairs[i][1])
+        order = [u, v]
+        rng.shuffle(order)                         # drawn for EVERY pair
+        if i not in flagged:
+            continue
+        sub = {u, v}
+        for node in order:
+            nb = list(nbrs[node])
+            if len(sub) + len(nb) < max_neighbors:
+                sub |= set(nb)
+            else:
+                rng.shuffle(nb)
+                sub |= set(nb[: max_neighbors - len(sub)])
+                break
+        sub.discard(u)
+        sub.discard(v)
+        out[i] = [u, v] + sorted(sub)
+    return out
+
+
 def _host_capped_nodes(pair, rowptr, col, max_neighbors, rng):     # (rowptr / col: successors for a directed graph)
     """the reference's truncation branch (SEAL/config/subgraph.py:118-135, hop = 1) with an explicit
     numpy RandomState; only used for the few capped pairs."""
@@ -295,8 +351,11 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
     """SEAL/config/subgraph.py:11-102 for hop in {0, 1, "auto"}: negatives first, then positives (:74).
     Returns (batch, labels, tags_size, tag_map, graph).  Tags in `batch.tags` are RAW; tag_map is
     the global compaction (:84-101) applied when features are built.
-    cap_policy: "device" (default) or "host" -- the few pairs that hit the 100-node cap are rebuilt
-    on the host with a seeded numpy RandomState walking the reference's own branch, then replayed."""
+    cap_policy: "device" (default: a counter-based hash of (seed, u, v) stands in for np.random.shuffle) or "host" --
+    the pairs that can hit the 100-node cap are rebuilt on the host SEED FOR SEED with the reference's own stream
+    (host_cap_node_lists: np.random.RandomState(seed), one shuffle([u, v]) per pair in the reference's pair order,
+    neighbour lists in networkx insertion order), then replayed on the device: under the same seed the truncated
+    subgraphs are the reference's own (tests/golden/seal_int.npz was generated under np.random.seed(2))."""
     graph = build_train_csr(positive, nodes_size, test_ratio, device, network_type)
     if hop == "auto":
         hop = auto_hop(positive, negative, graph, test_ratio)
@@ -311,9 +370,11 @@ def link2subgraph(positive, negative, nodes_size, test_ratio, hop, network_type=
         capped = batch.capped.bool()
         if bool(capped.any()):
             idx = torch.nonzero(capped).reshape(-1).cpu().numpy()
-            rp, cl = graph.rowptr.cpu().numpy(), graph.col.cpu().numpy()
-            rng = np.random.RandomState(seed)
-            lists = [_host_capped_nodes(pairs[i], rp, cl, max_neighbors, rng) for i in idx]
+            pos_h = positive.cpu().numpy() if torch.is_tensor(positive) else np.asarray(positive)
+            test_size = int(len(pos_h) * test_ratio)
+            train_pos = pos_h[: len(pos_h) - test_size] if test_size > 0 else pos_h          # as build_train_csr takes it
+            by_pair = host_cap_node_lists(pairs, idx, train_pos, max_neighbors, seed, directed=int(network_type) != 0)
+            lists = [by_pair[int(i)] for i in idx]
             rn = np.full((len(idx), MAXN), -1, dtype=np.int32)
             for k, l in enumerate(lists):
                 rn[k, : len(l)] = l

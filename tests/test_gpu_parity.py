@@ -2513,3 +2513,33 @@ def test_degree_partition_bucket_limit(dev, n, monkeypatch):
     monkeypatch.setattr(ops, "DEGREE_SORT_MIN", 1 << 62)
     want = ops.degree(idx, n)
     assert int(want.sum()) == E and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("directed", [False, True])
+def test_seal_host_cap_policy_seed_for_seed(dev, sl, golden_dir, directed):
+    """link2subgraph(cap_policy="host", seed=2): ALL 4202 subgraphs of the reference's own run under np.random.seed(2)
+    -- the truncated ones included -- come out of the product without a single node list of the reference being
+    replayed: node sets, canonical adjacency CRCs, tags after the global compaction, tags_size."""
+    from lpgnn_amd import seal
+    if directed:
+        sl = np.load(os.path.join(golden_dir, "seal_dir.npz"))
+    pos, neg = sl["positive"].astype(np.int64), sl["negative"].astype(np.int64)
+    batch, labels, T, tag_map, graph = seal.link2subgraph(pos, neg, 620, 0.1, 1, network_type=int(directed), seed=2,
+                                                          device=dev, cap_policy="host")
+    off, nodes_ref, tags_ref = sl["hop1_off"], sl["hop1_nodes"], sl["hop1_tags"]
+    n, nodes, tags, bits, tm = _np(batch.n), _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits), _np(tag_map)
+    assert T == int(sl["hop1_tags_size"]) and np.array_equal(n, np.diff(off))
+    assert np.array_equal(_np(labels).reshape(-1), sl["hop1_labels"])
+    if not directed:
+        assert (n >= 100).sum() >= 4                   # the pairs the cap really truncates are in there
+    contiguous = set(np.unique(tags[tags >= 0]).tolist()) == set(range(T))         # (:98: the tags are left alone then)
+    for g in range(len(n)):
+        nd, ref_nd = nodes[g, : n[g]], nodes_ref[off[g]:off[g + 1]]
+        assert nd[:2].tolist() == ref_nd[:2].tolist() and sorted(nd[2:].tolist()) == sorted(ref_nd[2:].tolist()), g
+        mapped = tags[g, : n[g]] if contiguous else tm[tags[g, : n[g]]]
+        want = dict(zip(ref_nd[2:].tolist(), tags_ref[off[g] + 2:off[g + 1]].tolist()))
+        assert dict(zip(nd[2:].tolist(), mapped[2:].tolist())) == want, g
+        a = _unpack_adj(bits[g], n[g])
+        p = np.concatenate([[0, 1], np.argsort(nd[2:], kind="stable") + 2])
+        a = a[p][:, p]
+        assert zlib.crc32(np.packbits(a.reshape(-1)).tobytes()) == int(sl["hop1_adj_crc_canon"][g]), g

@@ -1,7 +1,10 @@
 """CPU: host-side logic of the SEAL scoring path that needs no kernel -- the conv1d #2 / dense fold of the head, the
 per-graph hub bit matrix, the train-graph CSR.  (The kernels that consume them are held to the oracle in
 tests/test_gpu_parity.py.)"""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from lpgnn_amd import seal
@@ -145,3 +148,36 @@ def test_compact_tag_map_follows_the_reference_set_order():
         order = seal._cpython_set_order(lists)
         saw_unsorted |= order != sorted(order)
     assert saw_unsorted, "no case exercised a non-ascending set order"
+
+
+@pytest.mark.parametrize("name,directed", [("seal_int.npz", False), ("seal_dir.npz", True)])
+def test_host_cap_policy_reproduces_the_reference_stream(golden_dir, name, directed):
+    """seal.host_cap_node_lists under RandomState(2) == the node sets the reference itself produced under
+    np.random.seed(2) (tests/golden/*.npz, hop 1): every pair draws shuffle([u, v]) in the reference's pair order,
+    neighbour lists come in networkx insertion order, the truncation keeps the shuffled list's head
+    (SEAL/config/subgraph.py:118-135) -- nothing of the reference's output is replayed.  Flagged = every pair that
+    could truncate in EITHER visiting order (what the device kernel reports)."""
+    z = np.load(os.path.join(golden_dir, name))
+    pos, neg = z["positive"].astype(np.int64), z["negative"].astype(np.int64)
+    pairs = np.concatenate([neg, pos])
+    off, nodes = z["hop1_off"], z["hop1_nodes"]
+    train = pos[: len(pos) - int(len(pos) * 0.1)]
+    nb = seal._insertion_order_neighbours(train, set(pairs.reshape(-1).tolist()), directed)
+    flagged = []
+    for i, (u, v) in enumerate(pairs.tolist()):
+        du, dv, s0 = len(nb[u]), len(nb[v]), (1 if u == v else 2)
+        eu, ev = len(set(nb[u]) - {u, v}), len(set(nb[v]) - {u, v})
+        if s0 + du >= 100 or s0 + dv >= 100 or s0 + eu + dv >= 100 or s0 + ev + du >= 100:
+            flagged.append(i)
+    got = seal.host_cap_node_lists(pairs, flagged, train, 100, 2, directed)
+    truncated = 0
+    for i in flagged:
+        ref = nodes[off[i]:off[i + 1]]
+        assert ref[:2].tolist() == got[i][:2] and sorted(ref[2:].tolist()) == got[i][2:], i
+        full = ({*nb[int(pairs[i][0])], *nb[int(pairs[i][1])]} | {int(pairs[i][0]), int(pairs[i][1])})
+        truncated += len(ref) < len(full)
+    if not directed:
+        assert truncated >= 4                       # the undirected run has pairs the cap really bites
+    wrong = seal.host_cap_node_lists(pairs, flagged, train, 100, 3, directed)      # another seed: another truncation
+    if truncated:
+        assert any(wrong[i] != got[i] for i in flagged)
