@@ -411,6 +411,106 @@ def seal_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=5
     return out
 
 
+def _event_ms(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def config4_single_gpu_bench(device, iters=5):
+    """BASELINE configs[4] ("synthetic RMAT |V| = 10 M |E| = 200 M d = 256 CSR-SpMM ... MFMA dense feature update") at
+    FULL size on one GPU, fp32: the CSR SpMM and the dense 256 -> 256 update that follows it, each against its own
+    roofline (SpMM gather model; linear n (k + m) 4 bytes / 2 n k m flop)."""
+    from lpgnn_amd import ops
+    N, E, d = 10_000_000, 200_000_000, 256
+    g, x = make_rmat_problem(N, E, d, seed=4, device=device)
+    nnz = g.nnz()
+    y = torch.empty_like(x)
+    ms_spmm = _event_ms(lambda: g.spmm(x, out=y), iters)
+    alg = spmm_algorithmic_bytes(N, nnz, d, 4)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(11)
+    w = torch.randn((d, d), generator=gen, device=device) * 0.06
+    del x
+    out = torch.empty_like(y)
+    ms_lin = _event_ms(lambda: ops.linear(y, w, out=out), iters)
+    lin_bytes, lin_flop = N * (d + d) * 4, 2 * N * d * d
+    res = {"workload": f"RMAT |V|={N} |E|={nnz} d={d} fp32 on ONE GPU (configs[4] at full size, seed 4): Y = A X, then Y W^T",
+           "spmm_ms": ms_spmm, "spmm_gedges_per_s": nnz / ms_spmm / 1e6, "spmm_algorithmic_bytes": alg,
+           "spmm_frac_of_8TBs": alg / (ms_spmm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "dense_update_ms": ms_lin, "dense_update_GBs": lin_bytes / (ms_lin * 1e-3) / 1e9,
+           "dense_update_frac_of_8TBs": lin_bytes / (ms_lin * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "dense_update_TFLOPs_equiv": lin_flop / (ms_lin * 1e-3) / 1e12}
+    del g, y, out, w
+    torch.cuda.empty_cache()
+    return res
+
+
+def seal_ppa_bench(device, iters=5, B=50_000):
+    """BASELINE configs[3] ("ogbl-ppa SEAL", synthetic stand-in of SURVEY 8d config 4) on one GPU: |V| = 576 289,
+    30 326 273 undirected edges (seed 3), 50 K candidate pairs, d = 58 padded to 64; the scoring forward in bf16 and
+    fp32 storage, and the full-graph d = 64 SpMM.  X of that SpMM (147 MB) stays in the 256 MB Infinity Cache, so its
+    gather-model byte count is not HBM traffic: bound = infinity-cache, no HBM fraction is quoted."""
+    from lpgnn_amd import seal
+    N, E, D, k = 576_289, 30_326_273, 64, 18
+    ei = rmat_edges(N, E, 3, device)
+    graph = seal.build_train_csr(ei.t().contiguous(), N, test_ratio=0.0, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(2)
+    pairs = torch.randint(0, N, (B, 2), generator=gen, device=device)
+    emb = torch.randn((N, D), generator=gen, device=device)
+    emb[:, 58:] = 0.0                                                 # 58 real feature columns, padded to 64
+    probe = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0)
+    tag_map, T = seal.compact_tag_map(probe)
+    nn = probe.n.float()
+    stats = {"mean_n": float(nn.mean()), "max_n": int(nn.max()), "capped_frac": float(probe.capped.float().mean())}
+    del probe
+    torch.manual_seed(0)
+    gw32 = [torch.randn(a, b, device=device) * 0.1 for a, b in ((T + D, 32), (32, 32), (32, 32), (32, 1))]
+    hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, device=device) * 0.1, "conv1d_kernel_2": torch.randn(5, 16, 32, device=device) * 0.1,
+          "weight_1": torch.randn((k - 4) * 32, 128, device=device) * 0.1, "bias_1": torch.zeros(128, device=device),
+          "weight_2": torch.randn(128, 2, device=device), "bias_2": torch.zeros(2, device=device)}
+    k1 = hw["conv1d_kernel_1"].reshape(-1, 16)
+    out = {"workload": f"ppa-shaped SEAL scoring forward on ONE GPU: |V|={N}, {E} undirected edges, {B} candidate pairs, hop 1, "
+                       "d=58 padded to 64 (configs[3] stand-in)", "scored_edges": B, **stats}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        gw, e = [w.to(dt) for w in gw32], emb.to(dt)
+
+        def fwd():
+            batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0)
+            pooled = seal.score_stack(batch, tag_map, T, e, gw, k1, pool_k=k)
+            return seal.head(None, None, batch.node_off(), hw, pooled=pooled, check=False)[1]
+        ms = _time_ms(fwd, iters)
+        out[name] = {"ms_per_forward": ms, "scored_edges_per_s": B / (ms * 1e-3)}
+    out["extract_ms"] = _time_ms(lambda: seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=0), iters)
+    del graph, emb
+    torch.cuda.empty_cache()
+    import lpgnn_amd
+    g = lpgnn_amd.CSRGraph.from_edge_index(twowl_double(ei), N, N)
+    x = torch.randn((N, D), generator=gen, device=device)
+    ms = _event_ms(lambda: g.spmm(x), 10)
+    nnz = g.nnz()
+    alg = spmm_algorithmic_bytes(N, nnz, D, 4)
+    out["full_graph_spmm_d64"] = {"nnz": nnz, "ms": ms, "gedges_per_s": nnz / ms / 1e6, "bound": "infinity-cache",
+                                  "gather_model_GBs": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": None,
+                                  "note": "X is 147 MB (< the 256 MB Infinity Cache): the gather model's bytes are served "
+                                          "on-die, 1.1-1.2x the HBM peak would be quoted otherwise; compulsory HBM bytes = "
+                                          f"{spmm_compulsory_bytes(N, N, nnz, D, 4)}"}
+    return out
+
+
+def twowl_double(ei):
+    from lpgnn_amd import twowl
+    return twowl.double(ei)
+
+
 def combine_over_ranks(result, world, rank, timeout_s=180):
     """slowest rank's time through the c10d rendezvous store (no NCCL): every rank publishes its JSON, rank 0
     waits for the others with a timeout and reports what it got."""
@@ -759,7 +859,8 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(d)
             if not args.no_twowl:
-                for key, fn in (("twowl", twowl_forward_bench), ("twowl_scaled", twowl_scaled_bench), ("seal", seal_forward_bench)):
+                for key, fn in (("twowl", twowl_forward_bench), ("twowl_scaled", twowl_scaled_bench), ("seal", seal_forward_bench),
+                                ("seal_ppa", seal_ppa_bench), ("config4_single_gpu", config4_single_gpu_bench)):
                     try:
                         out[key] = fn(device)
                     except Exception as e:   # secondary figures must never take the headline down
@@ -779,6 +880,8 @@ def main():
               "seal_collab_100k_refmix_fp32": (((out.get("seal_sharded") or {}).get("refmix") or {}).get("fp32") or {}).get("scored_edges_per_s"),
               "seal_collab_100k_fp32": ((out.get("seal_sharded") or {}).get("fp32") or {}).get("scored_edges_per_s"),
               "seal_fb": (out.get("seal") or {}).get("scored_edges_per_s"),
+              "seal_ppa_50k": ((out.get("seal_ppa") or {}).get("bf16") or {}).get("scored_edges_per_s"),
+              "seal_ppa_50k_fp32": ((out.get("seal_ppa") or {}).get("fp32") or {}).get("scored_edges_per_s"),
               "twowl_fb": (out.get("twowl") or {}).get("scored_edges_per_s"),
               "twowl_fb_eager": (out.get("twowl") or {}).get("scored_edges_per_s_eager"),
               "twowl_fb_implicit_eager": ((out.get("twowl") or {}).get("implicit") or {}).get("scored_edges_per_s_eager"),

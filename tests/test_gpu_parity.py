@@ -2169,6 +2169,43 @@ def test_config3_ppa_shaped_graph(dev):
     pairs[220:260] = und[rng.integers(0, und.shape[0], 40)]     # true edges
     batch = seal.extract_subgraphs(pairs, graph, 1, cap_policy="device", seed=5)
     _check_extraction_vs_oracle(pairs, graph, batch, A, need_uncapped=150)
+    # (i') the conv stack + head AT THIS WIDTH (d = 58 real columns padded to 64; round 2 only timed it): fp32 storage
+    # against the fp64 oracle per sampled subgraph (layer-by-layer bound, u = 0), bf16 storage against the bound one 2^-8
+    # rounding per stored value implies, and the head on the fp32 stack
+    from oracle import aggregation as agg, seal_int
+    tag_map, T = seal.compact_tag_map(batch)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    emb = torch.randn((N, d), generator=gen, device=dev)
+    emb[:, 58:] = 0.0
+    w32 = [torch.randn(a, b, generator=gen, device=dev) * s_ for a, b, s_ in ((T + d, 32, 0.15), (32, 32, 0.4), (32, 32, 0.4), (32, 1, 0.5))]
+    _, _, x32 = seal.gnn_inputs(batch, tag_map, T, emb, build_csr=False)
+    z32, k32 = seal.graph_conv_stack(None, None, x32, w32, batch=batch)
+    hw = {"conv1d_kernel_1": torch.randn(96, 1, 16, generator=gen, device=dev) * 0.1,
+          "conv1d_kernel_2": torch.randn(5, 16, 32, generator=gen, device=dev) * 0.1,
+          "weight_1": torch.randn(14 * 32, 128, generator=gen, device=dev) * 0.1, "bias_1": torch.randn(128, generator=gen, device=dev) * 0.1,
+          "weight_2": torch.randn(128, 2, generator=gen, device=dev), "bias_2": torch.randn(2, generator=gen, device=dev)}
+    pre_y, score = seal.head(z32, k32, batch.node_off(), hw)
+    off_, n_, nodes_, tags_, bits_ = _np(batch.node_off()), _np(batch.n), _np(batch.nodes), _np(batch.tags), _np(batch.adj_bits)
+    tm_, emb64 = _np(tag_map), _np(emb).astype(np.float64)
+    w64, hw_np = [_np(w).astype(np.float64) for w in w32], {k: _np(v) for k, v in hw.items()}
+    zz, kk, py, sc = _np(z32).astype(np.float64), _np(k32).astype(np.float64), _np(pre_y), _np(score)
+    picks = list(range(0, 400, 9)) + [int(np.argmax(n_)), int(np.argmin(n_))]
+    for gi in picks:
+        nn = int(n_[gi])
+        a_t, dinv, xx = seal_int.gnn_inputs(_unpack_adj(bits_[gi], nn), tm_[tags_[gi, :nn]], T, emb64[nodes_[gi, :nn]])
+        assert np.array_equal(xx.astype(np.float32), _np(x32)[off_[gi]:off_[gi + 1]])
+        zc, key, ez, ek = seal_conv_oracle(a_t, dinv, xx, w64)
+        assert np.all(np.abs(zz[off_[gi]:off_[gi + 1]] - zc) <= ez) and np.all(np.abs(kk[off_[gi]:off_[gi + 1]] - key) <= ek), gi
+        want_y, want_s = agg.seal_head(zz[off_[gi]:off_[gi + 1]], kk[off_[gi]:off_[gi + 1]], hw_np)
+        by = 4 * TOL * agg.seal_head_mag(zz[off_[gi]:off_[gi + 1]], kk[off_[gi]:off_[gi + 1]], hw_np)
+        assert np.all(np.abs(py[gi] - want_y) <= by) and abs(sc[gi] - want_s) <= by.sum() / 4 + 1e-7
+    emb16, w16 = emb.bfloat16(), [w.bfloat16() for w in w32]
+    _, _, x16 = seal.gnn_inputs(batch, tag_map, T, emb16.float(), dtype=torch.bfloat16, build_csr=False)
+    z16, k16 = seal.graph_conv_stack(None, None, x16, w16, batch=batch)
+    worst = _check_seal_stack_bf16(batch, tag_map, T, emb16, w16, x16, z16, k16, picks)
+    print(f"configs[3] d = 58 -> 64 conv stack: bf16 worst error / derived bound = {worst:.3f}")
+    del x32, z32, x16, z16, emb, emb16
     for world in (2, 8):                                        # 8e (i): shards == one batch
         for r in range(world):
             lo, hi = ldist.source_range(len(pairs), world, r)
