@@ -630,6 +630,8 @@ def main():
                     help="how the per-rank partial aggregates are summed (N > 1); see lpgnn_amd/dist.py.  auto = the "
                          "sparse exchange (only the non-empty rows of the partial travel) when fewer than 3/4 of the "
                          "rows are non-empty and it reproduces the reduce-scatter on this graph, else reduce_scatter")
+    ap.add_argument("--wire", default="same", choices=["same", "bf16"],
+                    help="sparse exchange: dtype of the partial rows on the links (bf16 halves the bytes; fp32 accumulation at the owner)")
     ap.add_argument("--partition", default="source", choices=["source", "dst"],
                     help="source: the north star's source-edge partition + RCCL reduction (default). dst: every rank "
                          "owns the destination rows of its range and a replica of X -- no reduction at all (SURVEY 8e's "
@@ -697,7 +699,8 @@ def main():
         gen = torch.Generator(device=device)
         gen.manual_seed(1005 + rank)
         x = torch.randn((hi - lo, d), generator=gen, device=device).to(dtype)
-        runner = ldist.SourcePartitionedSpMM(ei, N, (lo, hi), n_blocks=args.blocks, collective=args.collective)
+        runner = ldist.SourcePartitionedSpMM(ei, N, (lo, hi), n_blocks=args.blocks, collective=args.collective,
+                                             wire_dtype=torch.bfloat16 if args.wire == "bf16" else None)
         del ei
         g = None
         if runner.collective == "sparse":
@@ -822,6 +825,22 @@ def main():
         if exchange_trial_ms is not None:
             out["config"]["exchange_trial_ms_per_step"] = exchange_trial_ms
         out["config"]["partial_rows_nonempty"] = round(runner.nonempty_fraction, 4)
+        # what the first real multi-GPU run needs to be diagnosable from one line: bytes this rank sends per step in the
+        # form that ran and in the alternatives, and per-stage SpMM time vs the time the stream waits for the exchange
+        out["config"]["bytes_on_links_per_step"] = {
+            "used": runner.bytes_on_links_per_step(d, dtype),
+            "reduce_scatter": runner.bytes_on_links_per_step(d, dtype, "reduce_scatter"),
+            "all_reduce": runner.bytes_on_links_per_step(d, dtype, "all_reduce"),
+            "wire_dtype": args.wire if runner.collective == "sparse" else "same"}
+        if runner.collective == "sparse":
+            try:
+                runner.profile = True
+                runner.forward(x)
+                out["config"]["stage_ms"] = runner.last_profile
+            except Exception as e:
+                out["config"]["stage_ms"] = {"error": repr(e)}
+            finally:
+                runner.profile = False
     seal_sharded = None
     if not args.no_twowl:
         del y

@@ -78,6 +78,10 @@ int lpg_scatter_add_f32(const float* src, const int64_t* index, int64_t E, int64
  * a shard in the sparse multi-GPU exchange, lpgnn_amd/dist.py): plain 16-byte read-modify-writes, no atomics. */
 int lpg_rows_add_f32(const float* src, const int64_t* index, int64_t E, int64_t d, float* out,
                      int64_t N, int32_t* err_flag, void* stream);
+/* the same for bf16 source rows (bf16 partials on the links, SURVEY 2b C1 "bf16 option"; build-defined): the owner's
+ * shard stays fp32 while the peers' rows are added, so the sum over the peers is rounded once at the end. */
+int lpg_rows_add_bf16(const uint16_t* src, const int64_t* index, int64_t E, int64_t d, float* out,
+                      int64_t N, int32_t* err_flag, void* stream);
 
 /* In-degree histogram, the reference's only direct torch_scatter call:
  * degree(ei, num_node) = scatter_add(ones_like(ei[1]), ei[1], dim_size=N)  [TwoWL/utils.py:8-10].

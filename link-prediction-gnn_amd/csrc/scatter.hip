@@ -150,7 +150,50 @@ __global__ __launch_bounds__(kBlock) void rows_add_f32_kernel(const float* __res
     }
   }
 }
+// the same with bf16 rows on the source side (the partials of a bf16 exchange): summed into the fp32 shard, so the
+// sum over the peers is rounded once at the end, not once per peer as a bf16 ring reduction does
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void rows_add_bf16_kernel(const uint16_t* __restrict__ src,
+                                                               const int64_t* __restrict__ index, int64_t E, int64_t d,
+                                                               float* __restrict__ out, int64_t N, int32_t* err_flag) {
+  const int64_t dv = d / VEC, total = E * dv;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t e = t / dv, c = (t - e * dv) * VEC;
+    const int64_t j = index[e];
+    if (j < 0 || j >= N) {
+      flag_error(err_flag, LPG_F_INDEX_RANGE);
+      continue;
+    }
+    if constexpr (VEC == 8) {
+      const uint4 a = *reinterpret_cast<const uint4*>(src + e * d + c);
+      float4* o = reinterpret_cast<float4*>(out + j * d + c);
+      const float4 b0 = o[0], b1 = o[1];
+      o[0] = make_float4(bf16_to_f32(a.x & 0xFFFFu) + b0.x, bf16_to_f32(a.x >> 16) + b0.y, bf16_to_f32(a.y & 0xFFFFu) + b0.z,
+                         bf16_to_f32(a.y >> 16) + b0.w);
+      o[1] = make_float4(bf16_to_f32(a.z & 0xFFFFu) + b1.x, bf16_to_f32(a.z >> 16) + b1.y, bf16_to_f32(a.w & 0xFFFFu) + b1.z,
+                         bf16_to_f32(a.w >> 16) + b1.w);
+    } else {
+      out[j * d + c] += bf16_to_f32(src[e * d + c]);
+    }
+  }
+}
 }  // namespace
+
+LPG_EXPORT int lpg_rows_add_bf16(const uint16_t* src, const int64_t* index, int64_t E, int64_t d, float* out, int64_t N,
+                                 int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(E >= 0 && N >= 0 && d >= 1, "rows_add_bf16: bad sizes");
+  if (E == 0) return LPG_OK;
+  LPG_REQUIRE(src && index && out, "rows_add_bf16: null pointer");
+  const bool wide = d % 8 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  if (wide)
+    hipLaunchKernelGGL(rows_add_bf16_kernel<8>, dim3(grid_for(E * d / 8)), dim3(kBlock), 0, as_stream(stream), src, index, E,
+                       d, out, N, err_flag);
+  else
+    hipLaunchKernelGGL(rows_add_bf16_kernel<1>, dim3(grid_for(E * d)), dim3(kBlock), 0, as_stream(stream), src, index, E, d,
+                       out, N, err_flag);
+  return check_launch("rows_add_bf16");
+}
 
 LPG_EXPORT int lpg_rows_add_f32(const float* src, const int64_t* index, int64_t E, int64_t d, float* out, int64_t N,
                                 int32_t* err_flag, void* stream) {

@@ -74,10 +74,17 @@ class SourcePartitionedSpMM:
     """
 
     def __init__(self, edge_index_local, n_nodes, src_range, n_blocks=4, edge_weight=None, group=None,
-                 block_spmm: Optional[Callable] = None, collective="reduce_scatter", world=None, rank=None):
+                 block_spmm: Optional[Callable] = None, collective="reduce_scatter", world=None, rank=None,
+                 wire_dtype=None):
+        """wire_dtype (sparse exchange only): torch.bfloat16 sends the partial rows in bf16 whatever x's dtype is (half
+        the bytes on the links -- what bounds the step on few GPUs); the owner adds the peers' rows into an fp32 shard
+        (lpg_rows_add_bf16), so the sum is rounded once at the end.  None: the rows travel in x's dtype."""
         import torch.distributed as dist
         self.n_nodes, self.src_range, self.group = int(n_nodes), src_range, group
         self.collective = collective
+        self.wire_dtype = wire_dtype
+        self.profile = False               # True: forward() records events around the stage SpMMs and the exchange waits
+        self.last_profile = None
         ready = dist.is_available() and dist.is_initialized()
         self.world = world if world is not None else (dist.get_world_size(group) if ready else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if ready else 0)
@@ -179,8 +186,8 @@ class SourcePartitionedSpMM:
         asyn = use_dist and backend != "gloo"
         bufs = self._buffers(d, dt, dev)
         mode = collective or self.collective
-        if mode == "sparse" and (not hasattr(self, "send_idx") or (x_local.is_cuda and dt != torch.float32)):
-            mode = "reduce_scatter"           # no plan (dense graph) or bf16 storage: the dense collective
+        if mode == "sparse" and not hasattr(self, "send_idx"):
+            mode = "reduce_scatter"           # no plan (dense graph): the dense collective
         if mode == "sparse":
             return self._forward_sparse(x_local, out, bufs, use_dist, asyn)
         rs = mode == "reduce_scatter"
@@ -265,9 +272,9 @@ class SourcePartitionedSpMM:
             return
         if y_stage.is_cuda:
             from . import ops
-            ops.rows_add_distinct(rows, idx, y_stage)                 # unique ids per peer: plain read-modify-writes
+            ops.rows_add_distinct(rows, idx, y_stage)                 # unique ids per peer: plain read-modify-writes (fp32 or bf16 rows)
         else:
-            y_stage.index_add_(0, idx, rows)
+            y_stage.index_add_(0, idx, rows.to(y_stage.dtype))
 
     def _exchange(self, send, s, use_dist, asyn):
         """all-to-all of the packed rows of stage s; returns (recv [sum(out_splits), d], work or None)."""
@@ -295,19 +302,46 @@ class SourcePartitionedSpMM:
             o += c
         return recv, None
 
+    def bytes_on_links_per_step(self, d, dtype, collective=None):
+        """bytes this rank SENDS to other ranks in one forward (the quantity xGMI bounds): the packed rows owned by
+        peers for the sparse exchange; (G - 1) / G of every stage buffer for a reduce-scatter, twice that for an
+        all-reduce (reduce-scatter + all-gather), whatever algorithm RCCL picks."""
+        mode = collective or self.collective
+        elt = torch.empty((), dtype=dtype).element_size()
+        if mode == "sparse" and hasattr(self, "in_splits"):
+            wire = torch.empty((), dtype=self.wire_dtype or dtype).element_size()
+            rows = sum(c for s in range(self.n_stages) for p, c in enumerate(self.in_splits[s]) if p != self.rank)
+            return int(rows * d * wire)
+        per = self.n_stages * self.world * self.sub * d * elt * (self.world - 1) // self.world
+        return int(per * (2 if mode == "all_reduce" else 1))
+
     def _forward_sparse(self, x_local, out, bufs, use_dist, asyn):
         d = x_local.shape[1]
         dev, dt = x_local.device, x_local.dtype
-        y = out if out is not None else torch.empty((self.shard, d), dtype=dt, device=dev)
+        wire = self.wire_dtype or dt
+        # the shard the peers' rows are added into is fp32 whenever rows travel or are stored in bf16
+        low = (torch.bfloat16, torch.float16)
+        acc_dt = torch.float32 if (wire in low or dt in low) else dt
+        y_out = out if out is not None else torch.empty((self.shard, d), dtype=dt, device=dev)
+        y = y_out if acc_dt == dt else torch.empty((self.shard, d), dtype=acc_dt, device=dev)
         y.zero_()
         pending = [None] * len(bufs)          # (work, stage, recv, send): recv lands in y once the work is done
+        prof = [] if (self.profile and x_local.is_cuda) else None
 
         def retire(slot):
             if pending[slot] is None:
                 return
             work, st, recv, _send = pending[slot]
+            if prof is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                prof.append(("wait0", st, e))
             if work is not None:
                 work.wait()
+            if prof is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                prof.append(("wait1", st, e))
             ys = y[st * self.sub:(st + 1) * self.sub]
             o = 0
             for p in range(self.world):                               # fixed order: rank 0's rows first
@@ -320,6 +354,10 @@ class SourcePartitionedSpMM:
             slot = s % len(bufs)
             retire(slot)
             buf = bufs[slot]
+            if prof is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                prof.append(("spmm0", s, e))
             if self.graphs_packed:
                 send = self.graphs_packed[s].spmm(x_local)            # straight into the packed rows (owner-major)
             elif self.block_spmm is not None:
@@ -328,11 +366,25 @@ class SourcePartitionedSpMM:
             else:
                 self.graphs[s].spmm(x_local, out=buf, skip_empty_rows=True)    # empty rows are never gathered
                 send = self._gather_rows(buf, self.send_idx[s])
+            if send.dtype != wire:
+                send = send.to(wire)                                  # fp32 partials rounded once for the wire
+            if prof is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                prof.append(("spmm1", s, e))
             recv, work = self._exchange(send, s, use_dist, asyn)      # overlaps the SpMM of stage s+1
             pending[slot] = (work, s, recv, send)
         for slot in range(len(bufs)):
             retire(slot)
-        return y
+        if y is not y_out:
+            y_out.copy_(y)                                            # one rounding of the finished sums
+        if prof is not None:
+            torch.cuda.synchronize()
+            ev = {(k, st): e for k, st, e in prof}
+            self.last_profile = {
+                "spmm_ms": [ev["spmm0", s].elapsed_time(ev["spmm1", s]) for s in range(self.n_stages)],
+                "exchange_wait_ms": [ev["wait0", s].elapsed_time(ev["wait1", s]) for s in range(self.n_stages)]}
+        return y_out
 
 
 class ShardedLinkScorer:

@@ -154,14 +154,20 @@ def scatter_add_rows(src: Optional[torch.Tensor], index: torch.Tensor, out: torc
 
 
 def rows_add_distinct(src: torch.Tensor, index: torch.Tensor, out: torch.Tensor):
-    """out[index[e], :] += src[e, :] where the entries of `index` are DISTINCT (no atomics); float32 [N, d]."""
+    """out[index[e], :] += src[e, :] where the entries of `index` are DISTINCT (no atomics); out float32 [N, d], src
+    float32 or bfloat16 (bf16 rows are widened as they are added: the accumulator stays fp32)."""
     lib = _lib.load()
     _need_gpu(index, out, src)
     index = _c(index, torch.int64)
-    src = _c(src, torch.float32)
     assert out.is_contiguous() and out.dtype == torch.float32
     N = out.shape[0]
     d = out.numel() // N if N > 0 else 1
+    if src.dtype == torch.bfloat16:
+        src = _c(src)
+        _lib.check(lib.lpg_rows_add_bf16(_ptr(src), _ptr(index), index.numel(), d, _ptr(out), N, _ptr(err_flag(out.device)),
+                                         _stream()), "rows_add_bf16")
+        return out
+    src = _c(src, torch.float32)
     _lib.check(lib.lpg_rows_add_f32(_ptr(src), _ptr(index), index.numel(), d, _ptr(out), N, _ptr(err_flag(out.device)),
                                     _stream()), "rows_add_f32")
     return out

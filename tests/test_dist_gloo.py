@@ -69,6 +69,23 @@ def _worker(rank, world, port, q):
             errs.append(float(np.abs(y - ref).max()))
         else:
             errs.append(float(np.abs(y - want).max()))
+    # bf16 partials on the wire (SURVEY 2b C1 "bf16 option"): the rows travel rounded to bf16 and are summed into an fp32
+    # shard; bytes on the links halve, the result is within one bf16 rounding of every exchanged row
+    op16 = ldist.SourcePartitionedSpMM(torch.from_numpy(mine), n, (lo, hi), n_blocks=5, block_spmm=block_spmm,
+                                       collective="sparse", wire_dtype=torch.bfloat16)
+    x32 = torch.from_numpy(x[lo:hi]).float()
+    y16 = op16.forward(x32).double().numpy()
+    y32 = op16.forward(x32, collective="reduce_scatter").double().numpy()
+    mag = np.zeros((op16.shard, d))
+    r0 = rank * op16.shard
+    rp_, cl_, _, _ = agg.coo_to_csr(ei[1], ei[0], n)
+    mag[: max(0, min(n, r0 + op16.shard) - r0)] = agg.csr_spmm(rp_, cl_, None, np.abs(x))[r0:r0 + op16.shard]
+    assert y16.dtype == np.float64 and np.all(np.abs(y16 - y32) <= 2.0 ** -8 * mag + 1e-6)
+    assert op16.bytes_on_links_per_step(d, torch.float32) * 2 == \
+        ldist.SourcePartitionedSpMM(torch.from_numpy(mine), n, (lo, hi), n_blocks=5, block_spmm=block_spmm,
+                                    collective="sparse").bytes_on_links_per_step(d, torch.float32)
+    dense = op16.bytes_on_links_per_step(d, torch.float32, collective="reduce_scatter")
+    assert dense == op16.n_stages * op16.sub * world * d * 4 * (world - 1) // world
     q.put((rank, max(errs), mine.shape[1]))
     dist.destroy_process_group()
 

@@ -54,6 +54,27 @@ def _rccl_worker(rank, world, port, q):
         out[collective] = (float((y - ref).abs().max()), float(ref.abs().max()), op.collective,
                            bool(op.graphs_packed), tuple(y.shape))
 
+    # bf16 on the links: (a) fp32 features with wire_dtype = bfloat16 (lpg_rows_add_bf16 into an fp32 shard), (b) bf16
+    # storage end to end (the bf16 SpMM writes the packed rows); both against the fp32 result within one bf16 rounding
+    # of what each row sums, and the profiled step reports per-stage SpMM / exchange-wait times
+    mag = lpgnn_amd.CSRGraph.from_edge_index(ei.to(dev), n, n).spmm(x.abs().to(dev))
+    r0 = rank * op.shard
+    magr = torch.zeros((op.shard, d), device=dev)
+    magr[: max(0, min(n, r0 + op.shard) - r0)] = mag[r0:r0 + op.shard]
+    ref = torch.zeros((op.shard, d), device=dev)
+    ref[: max(0, min(n, r0 + op.shard) - r0)] = full[r0:r0 + op.shard]
+    opw = ldist.SourcePartitionedSpMM(mine, n, (lo, hi), n_blocks=5, collective="sparse", wire_dtype=torch.bfloat16)
+    opw.profile = True
+    yw = opw.forward(x[lo:hi].to(dev))
+    ok_w = bool(torch.all((yw - ref).abs() <= 2.0 ** -8 * magr + 1e-6)) and yw.dtype == torch.float32
+    prof_ok = (opw.last_profile is not None and len(opw.last_profile["spmm_ms"]) == opw.n_stages
+               and len(opw.last_profile["exchange_wait_ms"]) == opw.n_stages and min(opw.last_profile["spmm_ms"]) > 0)
+    opb = ldist.SourcePartitionedSpMM(mine, n, (lo, hi), n_blocks=5, collective="sparse")
+    yb = opb.forward(x[lo:hi].to(dev).bfloat16())
+    ok_b = bool(torch.all((yb.float() - ref).abs() <= 3 * 2.0 ** -8 * magr + 1e-6)) and yb.dtype == torch.bfloat16
+    out["bf16_wire"] = (ok_w, ok_b, prof_ok, opw.bytes_on_links_per_step(d, torch.float32),
+                        opb.bytes_on_links_per_step(d, torch.float32))
+
     def score_fn(p):                                      # stands in for the single-GPU SEAL scorer
         return (p[:, 0] * 1000 + p[:, 1]).to(torch.float32)
 
@@ -96,6 +117,8 @@ def _run(world):
             err, scale, used, packed, _ = out[collective]
             assert used == collective and packed == (collective == "sparse")
             assert err <= 1e-5 * (scale + 1.0), (rank, collective, err)
+        ok_w, ok_b, prof_ok, bytes_w, bytes_f = out["bf16_wire"]
+        assert ok_w and ok_b and prof_ok and bytes_w * 2 == bytes_f and (bytes_f > 0) == (world > 1)
 
 
 def test_rccl_collectives_world1():
