@@ -109,7 +109,11 @@ struct RowCtxT {
   int j_lo, j_hi;      // column tiles the tile's subgraphs overlap
 };
 
-template <int NP, typename TIN, bool CAT>
+// K1: the head's conv1d #1 is fused (k1 != nullptr).  A template parameter only for the LDS budget: the concat-writing
+// fp32 variant without the head (what a caller who wants concat(Z1, Z2, Z3) as SEAL/model/gnn.py:63 produces it gets)
+// needs its 9 KB transposition slice but not the 9.8 KB of k1 fragments -- with both it was 89 KB, ONE workgroup per CU
+// instead of two ("desired occupancy was 2, final occupancy is 1"; 1.13 ms per 100 K candidates against 0.58 fused).
+template <int NP, typename TIN, bool CAT, bool K1>
 __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_conv_t2_kernel(
     const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
     const TIN* __restrict__ h1, int64_t ldh, const TIN* __restrict__ w2, const TIN* __restrict__ w3,
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
   __shared__ __attribute__((aligned(16))) uint16_t Hp[NP][32][HS];     // H^T as NP bf16 planes
   __shared__ __attribute__((aligned(16))) uint4 lut[256];             // byte -> 8 x bf16 {0, 1}
   __shared__ __attribute__((aligned(16))) uint4 Wb[2][NP][2][64];     // W_2, W_3: A fragments [layer][plane][k step][lane]
-  __shared__ __attribute__((aligned(16))) uint4 Kb[3][3][2][2][17];   // k1 slices (+ w4 in row 16 of layer 3): [layer][plane][k step][h][row]
+  __shared__ __attribute__((aligned(16))) uint4 Kb[K1 ? 3 : 1][K1 ? 3 : 1][2][2][K1 ? 17 : 1];   // k1 slices (+ w4 in row 16 of layer 3): [layer][plane][k step][h][row]
   __shared__ __attribute__((aligned(16))) uint4 W4b[NP][2][2];        // w4 alone (no head fusion): [plane][k step][h], row 0
   __shared__ uint32_t rinfo[RMAX];
   __shared__ int soff[WIN + 2];
@@ -552,17 +556,26 @@ int launch_conv2(const int64_t* node_off, const int32_t* first, int64_t n_window
   // eight workgroups per resident slot: the hardware dispatcher still balances windows of different cost (a grid of exactly
   // the resident slots waits for its unluckiest member; 1.33 x the slots runs a second, mostly empty round: bf16 0.44 -> 0.64 ms;
   // 4 x / 8 x / 16 x the slots: fused bf16 stack 0.470 / 0.458 / 0.475 ms, fp32 0.700 / 0.681 / 0.696)
-  static const int64_t slots_cat = resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, true>));
-  static const int64_t slots = resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, false>));
-  const int64_t cap = 8 * (cat ? slots_cat : slots);
+  static const int64_t slots_v[4] = {
+      resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, false, false>)),
+      resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, false, true>)),
+      resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, true, false>)),
+      resident_slots(reinterpret_cast<const void*>(&seal_conv_t2_kernel<NP, TIN, true, true>))};
+  const int64_t cap = 8 * slots_v[(cat ? 2 : 0) + (head_k1 ? 1 : 0)];
   const int64_t g = upper < cap ? (upper < 1 ? 1 : upper) : cap;
   const dim3 grid(static_cast<unsigned>(g)), blk(kConvBlock);
   const int64_t* total_ptr = n_windows >= 0 ? nullptr : node_off + n_subgraphs;
-  if (cat)
-    hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, true>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4, cat,
-                       ldc, key, head_k1, head_a16, fx, n_windows, total_ptr);
+  if (cat && head_k1)
+    hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, true, true>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4,
+                       cat, ldc, key, head_k1, head_a16, fx, n_windows, total_ptr);
+  else if (cat)
+    hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, true, false>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4,
+                       cat, ldc, key, head_k1, head_a16, fx, n_windows, total_ptr);
+  else if (head_k1)
+    hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, false, true>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4,
+                       cat, ldc, key, head_k1, head_a16, fx, n_windows, total_ptr);
   else
-    hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, false>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4,
+    hipLaunchKernelGGL((seal_conv_t2_kernel<NP, TIN, false, false>), grid, blk, 0, st, node_off, first, adj_bits, h1, ldh, w2, w3, w4,
                        cat, ldc, key, head_k1, head_a16, fx, n_windows, total_ptr);
   return check_launch("seal_conv_stack");
 }
