@@ -444,6 +444,12 @@ int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_
                        int32_t* tags, uint32_t* adj_bits, uint8_t* capped, uint8_t* tag_present,
                        const int32_t* hub_index, const uint32_t* hub_bits, int64_t hub_words,
                        int64_t hub_degree, int directed, int32_t* err_flag, void* stream);
+/* Measurement only (profiles/seal_phases.py; a -DLPG_TUNING build of the library, LPG_E_UNSUPPORTED otherwise): ticks of
+ * the 100 MHz wall clock the 128-thread teams of lpg_seal_subgraphs spent per phase since the last reset, summed over
+ * teams -- out8[0..6] = node set, row descriptors + filter, streamed lists, hub bit matrix, searches, DRNL, outputs;
+ * out8[7] = pairs handled by teams.  out8_host is HOST memory; synchronises the device. */
+int lpg_seal_phase_ticks(uint64_t* out8_host, int reset);
+
 /* Block-diagonal CSR of A~ = A + I over a batch, D^-1 = 1/rowsum(A~), and
  * X = [onehot(tag_map[tag], T) || emb[node]]  [SEAL/config/data.py:94-140].
  * node_off[B+1] = exclusive scan of n_nodes (host-computed or torch.cumsum);

@@ -31,51 +31,6 @@ __device__ __forceinline__ bool row_has(const int32_t* __restrict__ row, int len
   return lo < len && row[lo] == key;
 }
 
-// Both BFS sweeps of the DRNL labelling (from target 0 and from target 1) advance in the SAME level loop: the
-// three barriers of a level are shared, which halves the barrier count of the labelling (it is latency, not work).
-// vis / fr / nx hold two bit sets each: [0, WORDS) for source 0, [WORDS, 2 WORDS) for source 1.
-__device__ void bfs2_bits(const uint32_t (*adj)[WORDS], int n, int* dist0, int* dist1, uint32_t* vis, uint32_t* fr,
-                          uint32_t* nx) {
-  const int t = threadIdx.x;
-  if (t < MAXN) { dist0[t] = -1; dist1[t] = -1; }
-  if (t < 2 * WORDS) { vis[t] = 0; fr[t] = 0; nx[t] = 0; }
-  __syncthreads();
-  if (t == 0) {
-    dist0[0] = 0; vis[0] = 1u; fr[0] = 1u;                       // source 0 = vertex 0
-    dist1[1] = 0; vis[WORDS] = 2u; fr[WORDS] = 2u;               // source 1 = vertex 1
-  }
-  __syncthreads();
-  for (int level = 1; level <= n; ++level) {      // at most n-1 productive levels
-    if (t < n) {
-      const bool f0 = (fr[t >> 5] >> (t & 31)) & 1u, f1 = (fr[WORDS + (t >> 5)] >> (t & 31)) & 1u;
-      if (f0 || f1) {
-#pragma unroll
-        for (int w = 0; w < WORDS; ++w) {
-          const uint32_t m = adj[t][w];
-          if (m && f0) atomicOr(&nx[w], m);
-          if (m && f1) atomicOr(&nx[WORDS + w], m);
-        }
-      }
-    }
-    __syncthreads();
-    bool any = false;
-    uint32_t fresh[2 * WORDS];
-#pragma unroll
-    for (int w = 0; w < 2 * WORDS; ++w) {
-      fresh[w] = nx[w] & ~vis[w];
-      any |= fresh[w] != 0;
-    }
-    if (t < n) {
-      if ((fresh[t >> 5] >> (t & 31)) & 1u) dist0[t] = level;
-      if ((fresh[WORDS + (t >> 5)] >> (t & 31)) & 1u) dist1[t] = level;
-    }
-    __syncthreads();
-    if (t < 2 * WORDS) { vis[t] |= fresh[t]; fr[t] = fresh[t]; nx[t] = 0; }
-    __syncthreads();
-    if (!any) break;                               // uniform: every thread computed the same `any`
-  }
-}
-
 struct ListPlan {
   int32_t node;     // whose neighbour list
   int count;        // entries taken from it
@@ -144,6 +99,39 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {   // OR over the 64 
     hi |= __shfl_xor(hi, o, 64);
   }
   return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+// DRNL sweeps of a 128-thread team without a workgroup barrier: wave w runs the whole BFS from target w on its own --
+// lane l holds the 128-bit adjacency rows of vertices l and l + 64, a level is two wave-wide OR-reductions of the
+// frontier's rows.  (The level-synchronous version of rounds 1-2 spent three __syncthreads and up to n same-address LDS atomics
+// per level: a third of a heavy pair's time, profiles/seal_phases.py.)  Call with all 128 threads after a barrier that
+// publishes adj; dist0 / dist1 are complete after the caller's next barrier.
+__device__ __forceinline__ void bfs_team_waves(const uint32_t (*adj)[WORDS], int n, int* dist0, int* dist1) {
+  const int lane = threadIdx.x & 63, src = threadIdx.x >> 6;       // kSealBlock = 128: two waves, one source each
+  const int va = lane, vb = lane + 64;
+  uint64_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+  if (va < n) {
+    a_lo = adj[va][0] | (static_cast<uint64_t>(adj[va][1]) << 32);
+    a_hi = adj[va][2] | (static_cast<uint64_t>(adj[va][3]) << 32);
+  }
+  if (vb < n) {
+    b_lo = adj[vb][0] | (static_cast<uint64_t>(adj[vb][1]) << 32);
+    b_hi = adj[vb][2] | (static_cast<uint64_t>(adj[vb][3]) << 32);
+  }
+  uint64_t vis_lo = 1ull << src, vis_hi = 0ull, fr_lo = vis_lo, fr_hi = 0ull;
+  int da = lane == src ? 0 : -1, db = -1;
+  for (int level = 1; level <= n; ++level) {
+    const bool ina = (fr_lo >> lane) & 1ull, inb = (fr_hi >> lane) & 1ull;
+    const uint64_t n_lo = wave_or64((ina ? a_lo : 0ull) | (inb ? b_lo : 0ull)) & ~vis_lo;
+    const uint64_t n_hi = wave_or64((ina ? a_hi : 0ull) | (inb ? b_hi : 0ull)) & ~vis_hi;
+    if ((n_lo >> lane) & 1ull) da = level;
+    if ((n_hi >> lane) & 1ull) db = level;
+    vis_lo |= n_lo; vis_hi |= n_hi; fr_lo = n_lo; fr_hi = n_hi;
+    if (!(n_lo | n_hi)) break;                                     // wave-uniform
+  }
+  int* dist = src ? dist1 : dist0;
+  dist[va] = da;
+  dist[vb] = db;
 }
 
 // the rule both kinds of workgroup apply to decide who owns a pair (targets already range-checked)
@@ -311,13 +299,30 @@ __device__ __forceinline__ void wave_pair(
   if (lane == 0) { n_out[b] = n; capped_out[b] = 0; }
 }
 
+// -DLPG_TUNING builds only (profiles/seal_phases.py): where a 128-thread team's time goes, summed over the launch in ticks
+// of the 100 MHz wall clock -- [0] node set, [1] row descriptors + filter, [2] streamed lists, [3] hub bit matrix,
+// [4] searches, [5] DRNL, [6] outputs, [7] pairs handled by teams.  Adds a barrier per phase; release builds have none of it.
+#ifdef LPG_TUNING
+__device__ unsigned long long g_seal_phase[8];
+#define SEAL_PHASE(k)                                              \
+  do {                                                             \
+    __syncthreads();                                               \
+    if (threadIdx.x == 0) {                                        \
+      const unsigned long long now_ = wall_clock64();              \
+      ph_acc[k] += now_ - ph_t0;                                   \
+      ph_t0 = now_;                                                \
+    }                                                              \
+  } while (0)
+#else
+#define SEAL_PHASE(k) do { } while (0)
+#endif
+
 // LDS of a 128-thread team working on one pair
 struct BigPairLds {
   int32_t cand[2 * MAXN];
   int32_t nodes[MAXN];
   uint32_t adj[MAXN][WORDS];
   int dist0[MAXN], dist1[MAXN];
-  uint32_t vis[2 * WORDS], fr[2 * WORDS], nx[2 * WORDS];
   int s_n, s_capped, s_cnt[2], s_nbig, s_search;
   ListPlan s_list[2];
   int64_t rbase[MAXN];                  // per subgraph vertex: its neighbour list in the big graph
@@ -366,9 +371,6 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
   uint32_t (&adj)[MAXN][WORDS] = lds.team.adj;
   int (&dist0)[MAXN] = lds.team.dist0;
   int (&dist1)[MAXN] = lds.team.dist1;
-  uint32_t (&vis)[2 * WORDS] = lds.team.vis;
-  uint32_t (&fr)[2 * WORDS] = lds.team.fr;
-  uint32_t (&nx)[2 * WORDS] = lds.team.nx;
   int& s_n = lds.team.s_n;
   int& s_capped = lds.team.s_capped;
   int (&s_cnt)[2] = lds.team.s_cnt;
@@ -382,6 +384,9 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
   uint32_t (&member)[128] = lds.team.member;
   int (&hidx)[MAXN] = lds.team.hidx;
   const int t = threadIdx.x;
+#ifdef LPG_TUNING
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // thread 0's sums; added to the global table once per workgroup
+#endif
 
   for (int64_t iter = 0;; ++iter) {
     __syncthreads();
@@ -416,6 +421,10 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
       continue;
     }
     const int32_t u = static_cast<int32_t>(u64), v = static_cast<int32_t>(v64);
+#ifdef LPG_TUNING
+    unsigned long long ph_t0 = wall_clock64();
+    ph_acc[7] += 1ull;
+#endif
     if (t == 0) { s_n = 0; s_capped = 0; }
     for (int i = t; i < MAXN; i += kSealBlock) {
 #pragma unroll
@@ -542,6 +551,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
       continue;
     }
     const int was_capped = replay ? 0 : s_capped;
+    SEAL_PHASE(0);
 
     // ---- induced adjacency: bit (i, j) = A[nodes[i], nodes[j]], target entries cleared (:136-137)
     // Row i's neighbour list is STREAMED (16 lanes per row, coalesced) and each neighbour looked up among
@@ -588,6 +598,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
         atomicOr(&member[hsh >> 5], 1u << (hsh & 31));
       }
       __syncthreads();
+      SEAL_PHASE(1);
       constexpr int IT = 4;                              // consecutive items per thread and round (8: no gain on hub-rich subgraphs -- the
                                                          // phase is instruction-bound there, ~40 per entry -- and 7 % lost on the small ones)
       for (int p0 = IT * t; p0 < total; p0 += IT * kSealBlock) {
@@ -634,6 +645,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
         }
       }
     }
+    SEAL_PHASE(2);
     // what is left: hub x hub entries (neither list was streamed), or everything when a node list is replayed
     // A thread runs TWO binary searches in lockstep (the probes of a step are independent loads; four-way cost
     // a wave of occupancy in registers and lost more on the common small subgraphs than it won on the hub-rich ones): a hub-rich
@@ -649,30 +661,37 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
       if (t == 0) s_search = 0;
       if (t < nbig) hidx[t] = hub_index[nodes[big[t]]];           // one load per big row, all in flight together
       __syncthreads();
-      // four independent bit-matrix words in flight per thread (one dependent level instead of three per entry:
-      // a hub-rich capped subgraph has ~100 big rows = 10 K entries, 78 per thread)
-      const int np = nbig * nbig;
-      for (int p0 = t; p0 < np; p0 += 4 * kSealBlock) {
-        uint32_t wv[4];
-        int ii4[4], jj4[4];
-        bool ok4[4];
+      // Only the upper triangle a <= b of the (symmetric) hub x hub block is looked up and mirrored: entry p of the
+      // nbig (nbig + 1) / 2 is unranked with one v_sqrt_f32 (round 2 walked all nbig^2 index pairs with an integer
+      // division each and dropped half of them: this phase was 50-60 % of a team's time, profiles/seal_phases.py), and
+      // HW independent bit-matrix words are in flight per thread.
+      constexpr int HW = 8;
+      const int np = nbig * (nbig + 1) / 2;
+      const float fn = 2.0f * static_cast<float>(nbig) + 1.0f;
+      for (int p0 = t; p0 < np; p0 += HW * kSealBlock) {
+        uint32_t wv[HW];
+        int ij[HW];                                    // i | j << 8 | ok << 16
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < HW; ++q) {
           const int p = p0 + q * kSealBlock;
-          const int a = p < np ? p / nbig : 0, b2 = p < np ? p - a * nbig : 0;
-          const bool take = p < np && a <= b2;
-          const int ia = hidx[a], ib = hidx[b2];
-          if (take && (ia < 0 || ib < 0)) s_search = 1;
-          ok4[q] = take && ia >= 0 && ib >= 0;
-          ii4[q] = big[a];
-          jj4[q] = big[b2];
-          wv[q] = ok4[q] ? hub_bits[static_cast<int64_t>(ia) * hub_words + (ib >> 5)] : 0u;
-          if (ok4[q] && !((wv[q] >> (ib & 31)) & 1u)) ok4[q] = false;
+          const bool valid = p < np;
+          const int pc = valid ? p : 0;
+          int r = static_cast<int>((fn - sqrtf(fn * fn - 8.0f * static_cast<float>(pc))) * 0.5f);
+          r = r < 0 ? 0 : (r >= nbig ? nbig - 1 : r);
+          int off = r * nbig - ((r * (r - 1)) >> 1);
+          if (off > pc) { --r; off = r * nbig - ((r * (r - 1)) >> 1); }
+          else if (off + (nbig - r) <= pc) { off += nbig - r; ++r; }
+          const int b2 = r + (pc - off);
+          const int ia = hidx[r], ib = hidx[b2];
+          if (valid && (ia < 0 || ib < 0)) s_search = 1;
+          const bool ok = valid && ia >= 0 && ib >= 0;
+          wv[q] = ok ? hub_bits[static_cast<int64_t>(ia) * hub_words + (ib >> 5)] : 0u;
+          ij[q] = big[r] | (big[b2] << 8) | ((ok ? (1 + (ib & 31)) : 0) << 16);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = ii4[q], j = jj4[q];
-          if (ok4[q] && !((i == 0 && j == 1) || (i == 1 && j == 0))) {
+        for (int q = 0; q < HW; ++q) {
+          const int i = ij[q] & 0xFF, j = (ij[q] >> 8) & 0xFF, sh = ij[q] >> 16;
+          if (sh && ((wv[q] >> (sh - 1)) & 1u) && !((i == 0 && j == 1) || (i == 1 && j == 0))) {
             atomicOr(&adj[i][j >> 5], 1u << (j & 31));
             atomicOr(&adj[j][i >> 5], 1u << (i & 31));
           }
@@ -681,6 +700,7 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
       __syncthreads();
       search = s_search != 0;
     }
+    SEAL_PHASE(3);
     for (int p0 = t; search && p0 < nbig * ncol; p0 += 2 * kSealBlock) {
       int lo[2], hi[2], len[2], ii[2], jj[2];
       int32_t key[2];
@@ -728,9 +748,12 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     }
     __syncthreads();
 
+    SEAL_PHASE(4);
     // ---- DRNL (utils.py:35-54): two BFS sweeps on the bit matrix
-    bfs2_bits(adj, n, dist0, dist1, vis, fr, nx);
+    static_assert(kSealBlock == 128 && MAXN == 128 && WORDS == 4, "bfs_team_waves: two waves, 128-bit rows");
+    bfs_team_waves(adj, n, dist0, dist1);
     __syncthreads();
+    SEAL_PHASE(5);
     if (t < MAXN) {
       int tag = -1, nd = -1;
       if (t < n) {
@@ -754,7 +777,12 @@ __global__ __launch_bounds__(kSealBlock) __attribute__((amdgpu_waves_per_eu(8, 8
       for (int w = 0; w < WORDS; ++w) adj_out[(b * MAXN + t) * WORDS + w] = t < n ? adj[t][w] : 0u;
     }
     if (t == 0) { n_out[b] = n; capped_out[b] = static_cast<uint8_t>(was_capped); }
+    SEAL_PHASE(6);
   }
+#ifdef LPG_TUNING
+  if (t == 0 && ph_acc[7])
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_seal_phase[k], ph_acc[k]);
+#endif
 }
 
 // ---- block-diagonal CSR of A~ = A + I --------------------------------------------------------
@@ -1287,6 +1315,23 @@ LPG_EXPORT int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_
                      n_graph_nodes, pairs, B, hop, max_neighbors, replay, cap_policy, seed, nodes, n_nodes, tags, adj_bits, capped, err_flag,
                      tag_present, directed ? nullptr : hidx, hub_bits, static_cast<int>(hub_words), fused ? group : 0, directed, static_cast<int>(hub_degree));
   return check_launch("seal_subgraphs");
+}
+
+LPG_EXPORT int lpg_seal_phase_ticks(uint64_t* out8_host, int reset) {
+#ifdef LPG_TUNING
+  LPG_REQUIRE(out8_host, "seal_phase_ticks: null pointer");
+  LPG_HIP(hipDeviceSynchronize());
+  LPG_HIP(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_seal_phase), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    LPG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_seal_phase), zero, sizeof(zero)));
+  }
+  return LPG_OK;
+#else
+  (void)out8_host; (void)reset;
+  set_error("seal_phase_ticks: only in a -DLPG_TUNING build of the library");
+  return LPG_E_UNSUPPORTED;
+#endif
 }
 
 LPG_EXPORT int64_t lpg_seal_block_csr_bytes(int64_t total_nodes) {
