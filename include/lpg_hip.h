@@ -93,6 +93,13 @@ int lpg_rows_add_bf16(const uint16_t* src, const int64_t* index, int64_t E, int6
 int64_t lpg_degree_i64_bytes(int64_t E, int64_t N);
 int lpg_degree_i64(const int64_t* index, int64_t E, int64_t* out, int64_t N, void* workspace,
                    int64_t workspace_bytes, int32_t* err_flag, void* stream);
+/* The reference's own spelling of that histogram, scatter_add(ones_like(index), index, dim_size=N) [TwoWL/utils.py:10]:
+ * `ones` [E] is read beside the index inside the atomic-free paths (E >= 2^21, N > 16384) and *not_ones (device int32,
+ * caller-zeroed) is set when any entry differs from 1 -- the caller then discards `out` and takes
+ * lpg_scatter_add_i64 -- instead of a separate comparison pass over `ones` and its host sync. */
+int lpg_degree_i64_ones(const int64_t* index, const int64_t* ones, int64_t E, int64_t* out, int64_t N,
+                        void* workspace, int64_t workspace_bytes, int32_t* not_ones, int32_t* err_flag,
+                        void* stream);
 
 /* ---------------------------------------------------------------- COO -> CSR (once per graph)
  * Stable sort of the E edges by destination `dst` (row of the CSR): inside a row the original

@@ -56,15 +56,22 @@ DegWs carve(void* ws, int64_t E, int64_t N) {
   return w;
 }
 
+// `ones` (may be null): the source vector of scatter_add(src, index) that the caller BELIEVES is all ones -- the
+// reference's degree() spells the histogram that way (TwoWL/utils.py:8-10); it is read beside the index and any other
+// value sets *not_ones (the caller then falls back to the general kernel), instead of a separate pass and host sync.
 __global__ __launch_bounds__(kBlock) void narrow_kernel(const int64_t* __restrict__ index, int64_t E, int64_t N,
-                                                        uint32_t* __restrict__ keys, int32_t* err_flag) {
+                                                        uint32_t* __restrict__ keys, int32_t* err_flag,
+                                                        const int64_t* __restrict__ ones, int32_t* not_ones) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  bool odd = false;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < E; e += stride) {
     const int64_t v = index[e];
+    if (ones) odd |= ones[e] != 1;
     const bool ok = v >= 0 && v < N;
     if (!ok) flag_error(err_flag, LPG_F_INDEX_RANGE);
     keys[e] = ok ? static_cast<uint32_t>(v) : static_cast<uint32_t>(N);
   }
+  if (odd) atomicOr(not_ones, 1);
 }
 
 // run starts: first[key] = position.  One writer per key.
@@ -136,7 +143,8 @@ inline bool use_partition(int64_t E, int64_t N) {
 // counting sort of one 16 K-index chunk by bucket, in LDS; the int64 indices are read once, 2 bytes per key leave
 __global__ __launch_bounds__(kHistBlock) void local_partition_kernel(const int64_t* __restrict__ index, int64_t E, int64_t N,
                                                                      int nb, uint16_t* __restrict__ keys16,
-                                                                     uint16_t* __restrict__ tab, int32_t* err_flag) {
+                                                                     uint16_t* __restrict__ tab, int32_t* err_flag,
+                                                                     const int64_t* __restrict__ ones, int32_t* not_ones) {
   __shared__ uint32_t cnt[kMaxBuckets];
   __shared__ uint32_t cur[kMaxBuckets];
   __shared__ uint32_t wsum[kHistBlock / 64];
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(kHistBlock) void local_partition_kernel(const int64
   __syncthreads();
   uint32_t key[kKeysPerThread];
   const bool al16 = (reinterpret_cast<uintptr_t>(index) & 15) == 0;
-  bool bad = false;
+  bool bad = false, odd = false;
 #pragma unroll
   for (int i = 0; i < kKeysPerThread / 2; ++i) {
     const int64_t e = k0 + 2 * (static_cast<int64_t>(i) * kHistBlock + t);
@@ -158,6 +166,10 @@ __global__ __launch_bounds__(kHistBlock) void local_partition_kernel(const int64
     } else {
       if (e < E) v0 = index[e];
       if (e + 1 < E) v1 = index[e + 1];
+    }
+    if (ones) {
+      if (e < E) odd |= ones[e] != 1;
+      if (e + 1 < E) odd |= ones[e + 1] != 1;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -173,6 +185,7 @@ __global__ __launch_bounds__(kHistBlock) void local_partition_kernel(const int64
     }
   }
   if (bad) flag_error(err_flag, LPG_F_INDEX_RANGE);
+  if (odd) atomicOr(not_ones, 1);
   __syncthreads();
   // exclusive scan of the bucket counts (thread t <-> bucket t)
   const uint32_t mine = t < nb ? cnt[t] : 0u;
@@ -361,8 +374,28 @@ LPG_EXPORT int64_t lpg_degree_i64_bytes(int64_t E, int64_t N) {
   return use_partition(E, N) ? carve_part(nullptr, E, N).total : carve(nullptr, E, N).total;
 }
 
+namespace {
+int degree_impl(const int64_t* index, const int64_t* ones, int32_t* not_ones, int64_t E, int64_t* out, int64_t N, void* workspace,
+                int64_t workspace_bytes, int32_t* err_flag, void* stream);
+}
+
 LPG_EXPORT int lpg_degree_i64(const int64_t* index, int64_t E, int64_t* out, int64_t N, void* workspace,
                               int64_t workspace_bytes, int32_t* err_flag, void* stream) {
+  return degree_impl(index, nullptr, nullptr, E, out, N, workspace, workspace_bytes, err_flag, stream);
+}
+
+LPG_EXPORT int lpg_degree_i64_ones(const int64_t* index, const int64_t* ones, int64_t E, int64_t* out, int64_t N,
+                                   void* workspace, int64_t workspace_bytes, int32_t* not_ones, int32_t* err_flag,
+                                   void* stream) {
+  LPG_REQUIRE(E == 0 || (ones && not_ones), "degree_i64_ones: null pointer");
+  LPG_REQUIRE(E == 0 || (E >= (int64_t(1) << 21) && N > 16384 && E < (int64_t(1) << 31) && N < (int64_t(1) << 31) && workspace),
+              "degree_i64_ones: only the atomic-free paths check the source (E >= 2^21, N > 16384, workspace given)");
+  return degree_impl(index, ones, not_ones, E, out, N, workspace, workspace_bytes, err_flag, stream);
+}
+
+namespace {
+int degree_impl(const int64_t* index, const int64_t* ones, int32_t* not_ones, int64_t E, int64_t* out, int64_t N, void* workspace,
+                int64_t workspace_bytes, int32_t* err_flag, void* stream) {
   LPG_REQUIRE(E >= 0 && N >= 0, "degree_i64: bad sizes E=%lld N=%lld", (long long)E, (long long)N);
   if (E == 0) return LPG_OK;
   LPG_REQUIRE(index && out, "degree_i64: null pointer");
@@ -379,7 +412,7 @@ LPG_EXPORT int lpg_degree_i64(const int64_t* index, int64_t E, int64_t* out, int
     }
     const int nb = static_cast<int>(w.nb);
     hipLaunchKernelGGL(local_partition_kernel, dim3(static_cast<unsigned>(w.nchunks)), dim3(kHistBlock), 0, st, index, E, N, nb,
-                       w.keys16, w.tab, err_flag);
+                       w.keys16, w.tab, err_flag, ones, not_ones);
     hipLaunchKernelGGL(bucket_totals_kernel, dim3(static_cast<unsigned>(nb)), dim3(kBlock), 0, st, w.tab, w.nchunks, nb, w.totals);
     hipLaunchKernelGGL(part_bounds_kernel, dim3(1), dim3(kHistBlock), 0, st, w.totals, w.nchunks, nb, w.blk_off, w.gchunks);
     hipLaunchKernelGGL(part_count_kernel, dim3(static_cast<unsigned>(w.max_parts)), dim3(kHistBlock), 0, st, w.keys16, w.tab,
@@ -393,7 +426,7 @@ LPG_EXPORT int lpg_degree_i64(const int64_t* index, int64_t E, int64_t* out, int
     set_error("degree_i64: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)w.total);
     return LPG_E_WORKSPACE;
   }
-  hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, index, E, N, w.keys_in, err_flag);
+  hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, index, E, N, w.keys_in, err_flag, ones, not_ones);
   size_t tmp = w.sort_tmp_bytes;
   LPG_HIP(rocprim::radix_sort_keys(w.sort_tmp, tmp, w.keys_in, w.keys_out, static_cast<size_t>(E), 0u, bits_for(N), st,
                                    false));
@@ -401,3 +434,4 @@ LPG_EXPORT int lpg_degree_i64(const int64_t* index, int64_t E, int64_t* out, int
   hipLaunchKernelGGL(run_count_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.keys_out, E, N, w.first, out);
   return check_launch("degree_i64");
 }
+}  // namespace

@@ -173,6 +173,22 @@ def rows_add_distinct(src: torch.Tensor, index: torch.Tensor, out: torch.Tensor)
     return out
 
 
+def degree_if_ones(index: torch.Tensor, ones: torch.Tensor, out: torch.Tensor) -> bool:
+    """out[index[e]] += 1 through the atomic-free histogram while CHECKING that `ones` (the source of the reference's
+    scatter_add(ones_like(index), index) spelling) really is all ones -- inside the kernels that read the index, one
+    4-byte flag read at the end.  Returns False (and `out` is garbage) when it is not; big int64 lists only."""
+    lib = _lib.load()
+    _need_gpu(index, ones, out)
+    index, ones = _c(index, torch.int64), _c(ones, torch.int64)
+    E, n = index.numel(), out.shape[0]
+    nbytes = _lib.check(lib.lpg_degree_i64_bytes(E, n), "degree_bytes")
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=index.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=index.device)
+    _lib.check(lib.lpg_degree_i64_ones(_ptr(index), _ptr(ones), E, _ptr(out), n, _ptr(ws), nbytes, _ptr(flag),
+                                       _ptr(err_flag(index.device)), _stream()), "degree_i64_ones")
+    return int(flag.item()) == 0
+
+
 def degree(index: torch.Tensor, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """int64 histogram of `index` over [0, n): the reference's degree() (TwoWL/utils.py:8-10) without
     materialising the ones vector; lists of >= 2 M entries are counted without atomics (one radix pass over the high
