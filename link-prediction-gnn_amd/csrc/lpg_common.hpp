@@ -137,11 +137,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // bf16 <-> f32 (round to nearest even; plain casts keep NaN a NaN, see MI355X guide)
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(static_cast<uint32_t>(b) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<uint16_t>(u >> 16);
+// round to nearest even through gfx950's own conversion (v_cvt_pk_bf16_f32: ONE instruction; the bit-twiddled form --
+// NaN test, + 0x7fff + lsb, shift -- was six, sixteen times per tile and layer in the VALU-bound SEAL stack).  Same
+// result for every non-NaN input; NaN stays a (quiet) NaN.
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f)); }
+// two values -> one dword (a in the low half): one v_cvt_pk_bf16_f32 for the pair
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
 }  // namespace lpg

@@ -61,6 +61,24 @@ __device__ __forceinline__ void planes_of(float v, uint32_t (&p)[NP]) {
   }
 }
 
+// the planes of TWO values, packed (a in the low half of every dword): NP = 1 one v_cvt_pk_bf16_f32; NP = 3 the exact
+// truncation split with each plane's two upper halves merged by ONE v_perm_b32 -- (and, sub, and, sub) per value + three
+// perms per pair = 11 instructions, against 14 + 3 with a shift per plane and value and a shift-or per plane
+template <int NP>
+__device__ __forceinline__ void planes_pair(float a, float b, uint32_t (&pk)[NP]) {
+  if constexpr (NP == 1) {
+    pk[0] = pack_bf16x2(a, b);
+  } else {
+    const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    const float r1a = a - __uint_as_float(ua & 0xFFFF0000u), r1b = b - __uint_as_float(ub & 0xFFFF0000u);
+    const uint32_t ma = __float_as_uint(r1a), mb = __float_as_uint(r1b);
+    const float r2a = r1a - __uint_as_float(ma & 0xFFFF0000u), r2b = r1b - __uint_as_float(mb & 0xFFFF0000u);
+    pk[0] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);              // (hi16(b) << 16) | hi16(a)
+    pk[1] = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
+    pk[2] = __builtin_amdgcn_perm(__float_as_uint(r2b), __float_as_uint(r2a), 0x07060302u);
+  }
+}
+
 // plane pairs (value plane, weight plane) of a dense product, smallest terms first
 template <int NP> struct Terms;
 template <> struct Terms<1> {
@@ -143,11 +161,11 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
     uint32_t pk[NP][4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      uint32_t a[NP], b[NP];
-      planes_of<NP>(to_f32(w[acc_row(8 * s2 + 2 * jj, ln >> 5) * 32 + (ln & 31)]), a);
-      planes_of<NP>(to_f32(w[acc_row(8 * s2 + 2 * jj + 1, ln >> 5) * 32 + (ln & 31)]), b);
+      uint32_t pr[NP];
+      planes_pair<NP>(to_f32(w[acc_row(8 * s2 + 2 * jj, ln >> 5) * 32 + (ln & 31)]),
+                      to_f32(w[acc_row(8 * s2 + 2 * jj + 1, ln >> 5) * 32 + (ln & 31)]), pr);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) pk[p][jj] = a[p] | (b[p] << 16);
+      for (int p = 0; p < NP; ++p) pk[p][jj] = pr[p];
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) Wb[l][p][s2][ln] = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
@@ -163,11 +181,10 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
         const int fa = acc_row(8 * s2 + 2 * jj, hh), fb = acc_row(8 * s2 + 2 * jj + 1, hh);
         if (row < 16) { va = k1[(l * 32 + fa) * 16 + row]; vb = k1[(l * 32 + fb) * 16 + row]; }
         else if (l == 2) { va = to_f32(w4[fa]); vb = to_f32(w4[fb]); }
-        uint32_t a[3], b[3];
-        planes_of<3>(va, a);
-        planes_of<3>(vb, b);
+        uint32_t pr[3];
+        planes_pair<3>(va, vb, pr);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) pk[p][jj] = a[p] | (b[p] << 16);
+        for (int p = 0; p < 3; ++p) pk[p][jj] = pr[p];
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p) Kb[l][p][s2][hh][row] = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
@@ -177,11 +194,10 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
     uint32_t pk[NP][4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      uint32_t a[NP], b[NP];
-      planes_of<NP>(to_f32(w4[acc_row(8 * s2 + 2 * jj, hh)]), a);
-      planes_of<NP>(to_f32(w4[acc_row(8 * s2 + 2 * jj + 1, hh)]), b);
+      uint32_t pr[NP];
+      planes_pair<NP>(to_f32(w4[acc_row(8 * s2 + 2 * jj, hh)]), to_f32(w4[acc_row(8 * s2 + 2 * jj + 1, hh)]), pr);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) pk[p][jj] = a[p] | (b[p] << 16);
+      for (int p = 0; p < NP; ++p) pk[p][jj] = pr[p];
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) W4b[p][s2][hh] = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
@@ -218,11 +234,10 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
       if (row + 1 < nrows) piece(row + 1, kq, v1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        uint32_t a[NP], b[NP];
-        planes_of<NP>(v0[j], a);
-        planes_of<NP>(v1[j], b);
+        uint32_t pr[NP];
+        planes_pair<NP>(v0[j], v1[j], pr);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kq + j][row]) = a[p] | (b[p] << 16);
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kq + j][row]) = pr[p];
       }
     }
   };
@@ -336,8 +351,21 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hv, av[s2], acc, 0, 0, 0);
         }
     }
+    // tanh(acc * s) = 1 - 2 / (2^(acc * s2) + 1), two values at a time: the multiply, the add and the final fma are
+    // packed (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32), only exp2 and rcp stay per value -- 3.5 instead of 5
+    // instructions per value, sixteen values per tile and layer.  cx.one carries D^-1 * 2 log2(e).
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const f32x2 s2v = {cx.one, cx.one}, one2 = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = tanh_scaled(acc[i], cx.one);       // cx.one carries D^-1 * 2 log2(e)
+    for (int i = 0; i < 16; i += 2) {
+      f32x2 v = {acc[i], acc[i + 1]};
+      v = v * s2v;
+      v = f32x2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)} + one2;
+      v = f32x2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)};
+      v = __builtin_elementwise_fma(m2, v, one2);
+      acc[i] = v.x;
+      acc[i + 1] = v.y;
+    }
     return acc;
   };
 
@@ -381,8 +409,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
                 if constexpr (sizeof(TIN) == 4) {
                   *reinterpret_cast<float4*>(dst) = v;
                 } else {
-                  *reinterpret_cast<uint2*>(dst) = make_uint2(f32_to_bf16(v.x) | (static_cast<uint32_t>(f32_to_bf16(v.y)) << 16),
-                                                              f32_to_bf16(v.z) | (static_cast<uint32_t>(f32_to_bf16(v.w)) << 16));
+                  *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                 }
               }
             }
@@ -398,11 +425,10 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
         uint32_t pk[NP][4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          uint32_t a[NP], b[NP];
-          planes_of<NP>(z[8 * s2 + 2 * jj], a);
-          planes_of<NP>(z[8 * s2 + 2 * jj + 1], b);
+          uint32_t pr[NP];
+          planes_pair<NP>(z[8 * s2 + 2 * jj], z[8 * s2 + 2 * jj + 1], pr);
 #pragma unroll
-          for (int p = 0; p < NP; ++p) pk[p][jj] = a[p] | (b[p] << 16);
+          for (int p = 0; p < NP; ++p) pk[p][jj] = pr[p];
         }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -466,12 +492,15 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
         continue;
       }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {                 // lane = vertex 32 I + r, register i = feature acc_row(i, h)
-        uint32_t pl[NP];
-        planes_of<NP>(t == 0 ? hn0[i] : hn1[i], pl);
-        const int f = acc_row(i, h);
+      for (int i = 0; i < 16; i += 2) {              // lane = vertex 32 I + r, registers i, i + 1 = features acc_row(i, h), + 1
+        uint32_t pr[NP];
+        planes_pair<NP>(t == 0 ? hn0[i] : hn1[i], t == 0 ? hn0[i + 1] : hn1[i + 1], pr);
+        const int f = acc_row(i, h);                 // acc_row(i + 1, h) == f + 1 for even i
 #pragma unroll
-        for (int p = 0; p < NP; ++p) Hp[p][f][32 * I + r] = static_cast<uint16_t>(pl[p]);
+        for (int p = 0; p < NP; ++p) {
+          Hp[p][f][32 * I + r] = static_cast<uint16_t>(pr[p]);
+          Hp[p][f + 1][32 * I + r] = static_cast<uint16_t>(pr[p] >> 16);     // ds_write_b16_d16_hi: no shift
+        }
       }
     }
     __syncthreads();
