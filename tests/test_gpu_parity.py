@@ -2580,3 +2580,25 @@ def test_seal_host_cap_policy_seed_for_seed(dev, sl, golden_dir, directed):
         p = np.concatenate([[0, 1], np.argsort(nd[2:], kind="stable") + 2])
         a = a[p][:, p]
         assert zlib.crc32(np.packbits(a.reshape(-1)).tobytes()) == int(sl["hop1_adj_crc_canon"][g]), g
+
+
+@pytest.mark.parametrize("small", [True, False])
+def test_localwl_implicit_node_feature_branch(dev, tw, monkeypatch, small):
+    """LocalWLNet(use_node_feat=True) (TwoWL/model/model.py:47-51) over the structured tuple graph: the 1-WL stage comes
+    from Linear + LayerNorm instead of the degree embedding, the 2-WL stage is the per-node form; against the fp64
+    oracle over the explicit tuple graph, both device paths."""
+    from lpgnn_amd import twowl
+    from oracle import aggregation as agg
+    rng = np.random.default_rng(23)
+    ei, pred, ei2 = tw["test_ei"].astype(np.int64), tw["test_pred"].astype(np.int64), tw["test_ei2"].astype(np.int64)
+    pos1 = np.concatenate([ei.T, pred.T], axis=0)
+    feat = torch.from_numpy(rng.standard_normal((620, 48)).astype(np.float32)).to(dev)
+    torch.manual_seed(6)
+    mod = twowl.LocalWLNet(0, use_node_feat=True, node_feat=feat, channels_1wl=64, channels_2wl=32, depth1=2, depth2=2).to(dev).eval()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    monkeypatch.setattr(twowl, "_SMALL_PATH", small)
+    tg = twowl.tuple_graph(620, t(ei), t(pred))
+    y_len = pred.shape[1]
+    logits = twowl.test_forward(mod, torch.zeros(620, dtype=torch.int64, device=dev), t(ei), t(pos1), y_len, tg)
+    want = agg.localwl_forward(mod.export_params(), None, ei, pos1, ei.shape[1] + np.arange(y_len), ei2)
+    assert np.abs(_np(logits) - want).max() <= TOL * np.abs(want).max()
