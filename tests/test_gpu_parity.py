@@ -504,6 +504,26 @@ def test_sample_block_golden(dev, tw):
     assert np.array_equal(_np(ei2_new), tw["sb_ei2_new"])
     assert np.array_equal(_np(twowl.double(t(tw["split_train_pos"]))), tw["double_train_pos"])
     assert np.array_equal(_np(twowl.double(t(tw["double_idx_in"]), for_index=True)), tw["double_idx_out"])
+    # the same call on the structured tuple graph: the handle records the blocked ids; materialised, it is the
+    # reference's own blockei2 output (tests/golden: TwoWL/utils.py:48-50 run by the reference), and the training-step
+    # forward over it (TwoWL/model/train.py:32-37: x_new, ei_new, pos1, pos2 = blocked + negative tuples) equals the
+    # forward over the explicit ei2_new
+    from oracle import aggregation as agg
+    tg = twowl.tuple_graph(620, t(tw["train_ei"]), t(tw["train_pred"]))
+    ei_b, x_b, tg_b = twowl.sample_block(t(tw["sb_idx"]), 620, t(tw["train_ei"]), tg)
+    assert torch.equal(ei_b, ei_new) and torch.equal(x_b, x_new)
+    assert isinstance(tg_b, twowl.TupleGraph) and tg_b.plan().ok and np.array_equal(_np(tg_b.materialize()), tw["sb_ei2_new"])
+    torch.manual_seed(0)
+    mod = twowl.LocalWLNet(int(tw["sb_x_new"].max()) + 3, channels_1wl=32, channels_2wl=24, depth2=2).to(dev).eval()
+    E1 = tw["train_ei"].shape[1]
+    pos2 = np.concatenate([tw["sb_idx"].astype(np.int64), E1 + np.arange(len(tw["sb_idx"]))])
+    pos1 = np.concatenate([tw["train_ei"].T, tw["train_pred"].T], 0).astype(np.int64)
+    with torch.no_grad():
+        got = mod(x_new, ei_new, t(pos1), t(pos2), tg_b, True)
+        exp = mod(x_new, ei_new, t(pos1), t(pos2), ei2_new, True)
+    want = agg.localwl_forward(mod.export_params(), tw["sb_x_new"], tw["sb_ei_new"], pos1, pos2, tw["sb_ei2_new"].astype(np.int64))
+    scale = np.abs(want).max()
+    assert np.abs(_np(got) - want).max() <= TOL * scale and np.abs(_np(exp) - want).max() <= TOL * scale
 
 
 def test_get_ei2_edge_cases(dev):
@@ -2602,3 +2622,30 @@ def test_localwl_implicit_node_feature_branch(dev, tw, monkeypatch, small):
     logits = twowl.test_forward(mod, torch.zeros(620, dtype=torch.int64, device=dev), t(ei), t(pos1), y_len, tg)
     want = agg.localwl_forward(mod.export_params(), None, ei, pos1, ei.shape[1] + np.arange(y_len), ei2)
     assert np.abs(_np(logits) - want).max() <= TOL * np.abs(want).max()
+
+
+def test_localwl_implicit_degenerate_sizes(dev):
+    """the structured tuple graph at its edges: no graph tuples at all (every tuple a candidate: each is its own group),
+    no candidates (the readout names member tuples only), a single node -- against the fp64 oracle over the explicit
+    (possibly empty) tuple graph."""
+    from lpgnn_amd import twowl
+    from oracle import aggregation as agg, twowl_int
+    rng = np.random.default_rng(4)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cases = [(7, np.zeros((2, 0), np.int64), twowl_int.double(rng.integers(0, 7, size=(2, 5)))),       # no graph tuples
+             (9, twowl_int.double(rng.integers(0, 9, size=(2, 12))), np.zeros((2, 0), np.int64)),      # no candidates
+             (1, twowl_int.double(np.zeros((2, 2), np.int64)), twowl_int.double(np.zeros((2, 1), np.int64)))]   # one node, self loops
+    for N, pe, pr in cases:
+        E1, P = pe.shape[1], pe.shape[1] + pr.shape[1]
+        x_deg = np.bincount(pe[0], minlength=N).astype(np.int64) if E1 else np.zeros(N, np.int64)
+        torch.manual_seed(N)
+        mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=16, channels_2wl=8, depth2=2).to(dev).eval()
+        idx = np.arange(P)[: (P // 2) * 2]
+        pos1 = np.concatenate([pe.T, pr.T], 0)
+        ei2 = twowl_int.get_ei2(N, pe, pr)
+        want = agg.localwl_forward(mod.export_params(), x_deg, pe, pos1, idx, ei2)
+        tg = twowl.tuple_graph(N, t(pe), t(pr))
+        assert tg.plan().ok and tg.plan().Q == pr.shape[1]
+        with torch.no_grad():
+            got = _np(mod(t(x_deg), t(pe), t(pos1), t(idx), tg, True)).astype(np.float64)
+        assert got.shape == want.shape and np.abs(got - want).max() <= TOL * (np.abs(want).max() + 1e-30), N
