@@ -459,29 +459,57 @@ __global__ __launch_bounds__(kBlock) void tw_readout_kernel(int n_node, int Q, i
   const TwCoef ca = tw_coef(nm, sums, 0, cc), cr = tw_coef(nm, sums, 1, cc);
   const float ba = b_a[cc], br = b_r[cc], wc = live ? w[cc] : 0.f, bb = b0 ? b0[0] : 0.f;
   const int gw = (blockIdx.x * kBlock + threadIdx.x) >> 6, nw = (gridDim.x * kBlock) >> 6;
-  for (int j = gw; j < B; j += nw) {
-    const int64_t b = idx[2 * static_cast<int64_t>(j) + t];
-    const bool bad = b < 0 || b >= P;
-    if (__ballot(bad)) {
-      if (lane == 0) flag_error(err_flag, LPG_F_INDEX_RANGE);
-      continue;
-    }
-    const int q = qpos[b];
-    float ya, yr;
-    if (q < 0) {                                             // a member: b < E1
-      const int64_t s = pos_edge[b], e = pos_edge[E1 + b];
-      ya = tw_member(t_node[s * (2 * C) + cc], cnt[s], ba);
-      yr = tw_member(t_node[e * (2 * C) + C + cc], cnt[e], br);
-    } else {
-      ya = y_q[static_cast<int64_t>(q) * (2 * C) + cc];
-      yr = y_q[static_cast<int64_t>(q) * (2 * C) + C + cc];
-    }
-    const float row = tw_apply(ca, ya) + tw_apply(cr, yr);
-    const float other = __shfl_xor(row, 32);
-    float sacc = t == 0 ? row * other * wc : 0.f;
+  // a wave takes 64 consecutive pairs: lane j reads pair j's two tuple ids (16 bytes, coalesced) and their non-member
+  // positions once, then the pairs go through four at a time with their row loads issued together (walking the pairs
+  // one by one was three dependent round trips each: 29 us for 100 K pairs)
+  int ts = 1;                                                   // pairs per tile: ~8192 tiles (every wave slot of the chip), between one group and a wave's 64 lanes
+  while (ts < 64 && B > 8192 * ts) ts *= 2;
+  const int n_tiles = (B + ts - 1) / ts;
+  for (int tile = gw; tile < n_tiles; tile += nw) {
+    const int j0 = tile * ts, np_ = B - j0 < ts ? B - j0 : ts;
+    const int jl = lane < np_ ? lane : np_ - 1;
+    const longlong2 pr = *reinterpret_cast<const longlong2*>(idx + 2 * static_cast<int64_t>(j0 + jl));
+    const bool bad = pr.x < 0 || pr.x >= P || pr.y < 0 || pr.y >= P;
+    if (bad && lane < np_) flag_error(err_flag, LPG_F_INDEX_RANGE);
+    const int d_b0 = bad ? 0 : static_cast<int>(pr.x), d_b1 = bad ? 0 : static_cast<int>(pr.y);
+    const int d_q0 = P > 0 ? qpos[d_b0] : 0, d_q1 = P > 0 ? qpos[d_b1] : 0;
+    const uint64_t badmask = __ballot(bad);
+    for (int g0 = 0; g0 < np_; g0 += 4) {
+      float ya[4], yr[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-    if (lane == 0) out[j] = sacc + bb;
+      for (int u = 0; u < 4; ++u) {
+        if (g0 + u >= np_) {                                   // wave-uniform: a short last group (one pair per wave on small batches)
+          ya[u] = yr[u] = 0.f;
+          continue;
+        }
+        const int j = g0 + u;
+        const int b0 = __builtin_amdgcn_readlane(d_b0, j), b1 = __builtin_amdgcn_readlane(d_b1, j);
+        const int q0 = __builtin_amdgcn_readlane(d_q0, j), q1 = __builtin_amdgcn_readlane(d_q1, j);
+        const int b = t ? b1 : b0, q = t ? q1 : q0;
+        if (q0 >= 0 && q1 >= 0) {                              // wave-uniform: both tuples are non-members (the scoring case)
+          ya[u] = y_q[static_cast<int64_t>(q) * (2 * C) + cc];
+          yr[u] = y_q[static_cast<int64_t>(q) * (2 * C) + C + cc];
+        } else if (q < 0) {                                    // a member: b < E1
+          const int64_t s = pos_edge[b], e = pos_edge[E1 + b];
+          ya[u] = tw_member(t_node[s * (2 * C) + cc], cnt[s], ba);
+          yr[u] = tw_member(t_node[e * (2 * C) + C + cc], cnt[e], br);
+        } else {
+          ya[u] = y_q[static_cast<int64_t>(q) * (2 * C) + cc];
+          yr[u] = y_q[static_cast<int64_t>(q) * (2 * C) + C + cc];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (g0 + u >= np_) continue;
+        const float row = tw_apply(ca, ya[u]) + tw_apply(cr, yr[u]);
+        const float other = __shfl_xor(row, 32);
+        float sacc = t == 0 ? row * other * wc : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        const int j = g0 + u;
+        if (lane == 0 && j < np_ && !((badmask >> j) & 1ull)) out[j0 + j] = sacc + bb;
+      }
+    }
   }
 }
 
@@ -660,7 +688,10 @@ LPG_EXPORT int lpg_tuple_readout_f32(int64_t n_node, int64_t Q, int64_t C, int64
   TwNorm nm;
   LPG_REQUIRE(make_norm(&nm, part, n_part, P, gw_a, gb_a, gms_a, eps_a, relu_a, gw_r, gb_r, gms_r, eps_r, relu_r),
               "tuple_readout: 1 <= n_part <= %d partial blocks needed", kTwMaxPart);
-  hipLaunchKernelGGL(tw_readout_kernel, dim3(grid_for(B * 64)), dim3(kBlock), 0, as_stream(stream), static_cast<int>(n_node),
+  LPG_REQUIRE(reinterpret_cast<uintptr_t>(idx) % 16 == 0, "tuple_readout: idx must be 16-byte aligned");
+  int ts = 1;
+  while (ts < 64 && B > 8192 * ts) ts *= 2;
+  hipLaunchKernelGGL(tw_readout_kernel, dim3(grid_for(ceil_div(B, ts) * 64)), dim3(kBlock), 0, as_stream(stream), static_cast<int>(n_node),
                      static_cast<int>(Q), static_cast<int>(C), E1, P, pos_edge, t_node, y_q, cnt, qpos, nm, b_a, b_r, idx,
                      static_cast<int>(B), w, b0, out, err_flag);
   return check_launch("tuple_readout");

@@ -857,6 +857,8 @@ def tuple_readout(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, 
     """TwoWL/model/model.py:78-83 over the last 2-WL layer (GraphNorm + ReLU applied on load) -> [B, 1] logits"""
     C = t_node.shape[1] // 2
     idx = _c(idx.reshape(-1), torch.int64)
+    if idx.data_ptr() % 16:
+        idx = idx.clone()                    # the kernel reads a pair's two ids as one 16-byte piece
     _need_gpu(t_node, y_q, idx, w, b0)
     B = idx.numel() // 2
     out = torch.empty((B, 1), dtype=torch.float32, device=t_node.device)
