@@ -251,6 +251,13 @@ def twowl_scaled_bench(device, iters=20, n_pairs=100_000):
                 ms2 = _time_ms(stage, iters)
                 res[mode] = {"ms_per_forward": ms, "scored_edges_per_s": n_pairs / (ms * 1e-3), "two_wl_stage_ms": ms2,
                              "one_wl_stage_ms": ms - ms2}
+                if mode == "node":
+                    try:                                     # the same forward replayed from one hipGraph (no launch gaps)
+                        cap = twowl.CapturedForward(mod, x_deg, pos_edge, tg.pos1, Ep, tg)
+                        assert torch.equal(cap(), ref)
+                        res[mode]["ms_per_forward_hipgraph"] = _time_ms(cap, iters)
+                    except Exception as e:
+                        res[mode]["ms_per_forward_hipgraph"] = repr(e)
                 if mode == "operator":
                     # row passes over [P, C2] fp32 in the 2-WL stage: pair product (1 write), per orientation the group
                     # sums (1 read) and the broadcast (1 write), GraphNorm (2 reads, 1 write; the second also reads the sum)
@@ -905,6 +912,8 @@ def main():
               "twowl_fb_eager": (out.get("twowl") or {}).get("scored_edges_per_s_eager"),
               "twowl_fb_implicit_eager": ((out.get("twowl") or {}).get("implicit") or {}).get("scored_edges_per_s_eager"),
               "twowl_collab_100k": (out.get("twowl_scaled") or {}).get("scored_edges_per_s"),
+              "twowl_collab_100k_hipgraph": (lambda m: 100_000 / (m * 1e-3) if isinstance(m, float) else None)(
+                  (out.get("twowl_scaled") or {}).get("ms_per_forward_hipgraph")),
               "twowl_collab_100k_operator_form": ((out.get("twowl_scaled") or {}).get("operator_form") or {}).get("scored_edges_per_s")}
         out["scored_edges_per_s"] = {k: v for k, v in sc.items() if v is not None}
         print(json.dumps(out), flush=True)
