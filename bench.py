@@ -518,6 +518,52 @@ def twowl_double(ei):
     return twowl.double(ei)
 
 
+def twowl_sharded_bench(device, world, rank, dist, pairs_per_gpu=100_000, iters=10):
+    """TwoWL at N GPUs: the collab-shaped graph of twowl_scaled, 100 K candidate pairs PER GPU (weak scaling), candidate
+    tuples sharded across ranks (lpgnn_amd.dist.ShardedTwoWLScorer): graph, model and node tables replicated, and -- the
+    candidates are not independent, GraphNorm's statistics run over all tuples -- one RCCL all-reduce of a [2, 64] fp64
+    block per 2-WL layer.  Two phases so that no rank can skip a collective its peers have entered: everything that can
+    fail locally first (graph, plan, one forward without the exchange), one agreement, only then the timed forwards."""
+    from lpgnn_amd import twowl
+    from lpgnn_amd import dist as ldist
+    N, E, C1, C2 = 235_868, 1_285_465, 256, 32
+    ok, err, sc, x_deg = 1, None, None, None
+    try:
+        pos_edge = twowl.double(rmat_edges(N, E, 1, device))
+        gen = torch.Generator(device=device)
+        gen.manual_seed(2)
+        pred_edge = twowl.double(torch.randint(0, N, (2, pairs_per_gpu * world), generator=gen, device=device))   # identical on every rank
+        x_deg = twowl.degree(pos_edge, N)
+        torch.manual_seed(0)
+        mod = twowl.LocalWLNet(int(x_deg.max()), channels_1wl=C1, channels_2wl=C2).to(device).eval()
+        sc = ldist.ShardedTwoWLScorer(mod, N, pos_edge, pred_edge, world=world, rank=rank)
+        use = sc.collective
+        sc.collective = False
+        sc(x_deg)                                     # graph, plan, every kernel once -- no exchange yet
+        torch.cuda.synchronize()
+        sc.collective = use
+    except Exception as e:
+        ok, err = 0, repr(e)
+    if dist is not None and world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            return {"error": err or "another rank failed before the first exchange"}
+    elif not ok:
+        return {"error": err}
+    ms = _time_ms(lambda: sc(x_deg), iters)
+    if dist is not None and world > 1:
+        tmax = torch.tensor([ms], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ms = float(tmax.item())
+    B = pairs_per_gpu * world
+    return {"workload": f"collab-shaped TwoWL scoring forward, candidate tuples sharded: |V|={N}, {2 * E} graph tuples, {pairs_per_gpu} "
+                        f"candidate pairs per GPU x {world}, C1={C1} C2={C2} depth 1/1; graph, model and node tables replicated, "
+                        "GraphNorm statistics all-reduced (1 KB per 2-WL layer); value = all pairs / slowest rank's time",
+            "scored_edges": B, "ms_per_forward": ms, "scored_edges_per_s": B / (ms * 1e-3),
+            "exchange_bytes_per_forward": sc.bytes_per_layer * len(sc.mod.conv2s) if world > 1 else 0}
+
+
 def combine_over_ranks(result, world, rank, timeout_s=180):
     """slowest rank's time through the c10d rendezvous store (no NCCL): every rank publishes its JSON, rank 0
     waits for the others with a timeout and reports what it got."""
@@ -861,9 +907,15 @@ def main():
             seal_sharded = combine_over_ranks(seal_sharded, world, rank)
         except Exception as e:
             seal_sharded = {"error": "combine: " + repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            twowl_sharded = twowl_sharded_bench(device, world, rank, dist)
+        except Exception as e:
+            twowl_sharded = {"error": repr(e)}
     if rank == 0:
         if seal_sharded is not None:
             out["seal_sharded"] = seal_sharded
+            out["twowl_sharded"] = twowl_sharded
         if runner_was_none and world == 1:
             alg = spmm_algorithmic_bytes(N, nnz, d, elt)
             comp = spmm_compulsory_bytes(N, N, nnz, d, elt)
@@ -911,6 +963,7 @@ def main():
               "twowl_fb": (out.get("twowl") or {}).get("scored_edges_per_s"),
               "twowl_fb_eager": (out.get("twowl") or {}).get("scored_edges_per_s_eager"),
               "twowl_fb_implicit_eager": ((out.get("twowl") or {}).get("implicit") or {}).get("scored_edges_per_s_eager"),
+              "twowl_collab_100k_per_gpu_sharded": (out.get("twowl_sharded") or {}).get("scored_edges_per_s"),
               "twowl_collab_100k": (out.get("twowl_scaled") or {}).get("scored_edges_per_s"),
               "twowl_collab_100k_hipgraph": (lambda m: 100_000 / (m * 1e-3) if isinstance(m, float) else None)(
                   (out.get("twowl_scaled") or {}).get("ms_per_forward_hipgraph")),

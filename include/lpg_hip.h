@@ -294,7 +294,7 @@ int lpg_small_readout_f32(const float* ya, const float* yr, int64_t P, int64_t C
  * TwoWL/model/train.py:54-60) as ONE call: `block` (HOST memory, n_words int64 words) lists the forward's launches in
  * order as { op, a_0 .. a_{k-1} } -- op 1: lpg_embedding_graphnorm_f32 (k = 12), 2: lpg_small_linear_t_f32 (27),
  * 3: lpg_small_gcn_f32 (20), 4: lpg_small_readout_f32 (23), 5: lpg_small_gcn_embed_f32 (21), 6: lpg_tuple_layer_f32 (19),
- * 7: lpg_tuple_readout_f32 (30), 8: lpg_tuple_ax_small_f32 (15); a_i = that entry point's i-th argument (pointers and
+ * 7: lpg_tuple_readout_f32 (31), 8: lpg_tuple_ax_small_f32 (15); a_i = that entry point's i-th argument (pointers and
  * integers as they are, `float eps` as the bit pattern of a double; the trailing stream argument is left out).  Every
  * launch goes through the same entry point as the one-by-one path and is enqueued on `stream`: same kernels, same
  * results, one host call per forward instead of six (the forward is launch-bound: 205 -> ~60 us eager).
@@ -351,12 +351,16 @@ int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8
  *   their group sum is x[i] * (A x)[i].  mode 2:
  *   x = (F_a | F_r) [n_node, 2C] from lpg_tuple_apply_f32, ax = A x [n_node, 2C], hq_prev [Q, C].
  *   Writes t_node [n_node, 2C] = (T_a | T_r) (may be NULL), y_q [Q, 2C] = the non-member rows (bias added) and
- *   part [n_blocks][2][64] (fp64 sums of y and y^2 over ALL P rows, column = orientation * 32 + c), n_blocks =
+ *   part [2 * n_blocks][2][64]: fp64 sums of y and y^2 (column = orientation * 32 + c) -- even blocks over the member rows
+ *   (through the node rows), odd blocks over the non-member rows; all of them together cover ALL P rows.  n_blocks =
  *   lpg_tuple_layer_blocks(n_node, Q).  Atomic-free, fixed order.
- * lpg_tuple_fold_f64: part [n_in][2][64] -> out [n_out][2][64] (consumers take at most 64 partial blocks).
+ * lpg_tuple_fold_f64: part [n_in][2][64] -> out [n_out][2][64], out[j] = sum of blocks j, j + n_out, ... (consumers
+ *   take at most 64 partial blocks).  n_out = 2 keeps the member rows' and the non-member rows' sums apart: with the
+ *   candidate list sharded over GPUs the second block is summed across ranks (lpgnn_amd.dist.ShardedTwoWLScorer).
  * lpg_tuple_apply_f32: GraphNorm + ReLU between two layers: ff [n_node, 2C], hq [Q, C] = f_a(y_a) + f_r(y_r).
  * lpg_tuple_readout_f32: model.py:78-83 with the last layer's GraphNorm + ReLU applied on load; idx may name any
- *   tuple (member rows are F_a[start] + F_r[end]).
+ *   tuple (member rows are F_a[start] + F_r[end]).  n_rows = the rows `part` covers (P; more when the candidate list is
+ *   sharded over GPUs and `part` holds the sums over all ranks' candidates).
  * lpg_tuple_bcast_f32: the broadcast of the operator form -- GCNConv(x, orientation) for an arbitrary [P, C] input:
  *   y[b] = t_node[node(b)] / cnt + bias (member), t_node[node(b)] / sqrt(cnt (cnt + 1)) + hq[q] / (cnt + 1) + bias
  *   (otherwise); t_node = (group sums of x over the members) W^T, hq = x[non-members] W^T. */
@@ -386,11 +390,11 @@ int lpg_tuple_apply_f32(int64_t n_node, int64_t Q, int64_t C, const float* t_nod
 int lpg_tuple_readout_f32(int64_t n_node, int64_t Q, int64_t C, int64_t E1, int64_t P,
                           const int64_t* pos_edge, const float* t_node, const float* y_q,
                           const int32_t* cnt, const int32_t* qpos, const double* part, int64_t n_part,
-                          const float* gw_a, const float* gb_a, const float* gms_a, float eps_a,
-                          int relu_a, const float* gw_r, const float* gb_r, const float* gms_r,
-                          float eps_r, int relu_r, const float* b_a, const float* b_r,
-                          const int64_t* idx, int64_t B, const float* w, const float* b0, float* out,
-                          int32_t* err_flag, void* stream);
+                          int64_t n_rows, const float* gw_a, const float* gb_a, const float* gms_a,
+                          float eps_a, int relu_a, const float* gw_r, const float* gb_r,
+                          const float* gms_r, float eps_r, int relu_r, const float* b_a,
+                          const float* b_r, const int64_t* idx, int64_t B, const float* w,
+                          const float* b0, float* out, int32_t* err_flag, void* stream);
 int lpg_tuple_bcast_f32(int64_t P, int64_t C, int orient, const int32_t* tnode, const int32_t* cnt,
                         const int32_t* qpos, const float* t_node, int64_t ldt, const float* hq,
                         int64_t ldh, const float* bias, float* y, int64_t ldy, void* stream);

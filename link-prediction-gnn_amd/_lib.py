@@ -105,7 +105,7 @@ class options:
 _REC_OPS = {"lpg_embedding_graphnorm_f32": (1, 12, (8,)), "lpg_small_linear_t_f32": (2, 27, (25,)),
             "lpg_small_gcn_f32": (3, 20, ()), "lpg_small_readout_f32": (4, 23, (16,)),
             "lpg_small_gcn_embed_f32": (5, 21, (12,)), "lpg_tuple_layer_f32": (6, 19, ()),
-            "lpg_tuple_readout_f32": (7, 30, (15, 20)), "lpg_tuple_ax_small_f32": (8, 15, (12,))}
+            "lpg_tuple_readout_f32": (7, 31, (16, 21)), "lpg_tuple_ax_small_f32": (8, 15, (12,))}
 _rec = None            # while recording: {"words": [...], "keep": [...]}
 
 

@@ -770,7 +770,7 @@ LPG_EXPORT int lpg_twowl_forward_small(const int64_t* block, int64_t n_words, vo
   while (i < n_words) {
     const int64_t op = block[i];
     const int64_t* a = block + i + 1;
-    const int64_t need = op == 1 ? 12 : op == 2 ? 27 : op == 3 ? 20 : op == 4 ? 23 : op == 5 ? 21 : op == 6 ? 19 : op == 7 ? 30 : op == 8 ? 15 : -1;
+    const int64_t need = op == 1 ? 12 : op == 2 ? 27 : op == 3 ? 20 : op == 4 ? 23 : op == 5 ? 21 : op == 6 ? 19 : op == 7 ? 31 : op == 8 ? 15 : -1;
     LPG_REQUIRE(need > 0 && i + 1 + need <= n_words, "twowl_forward_small: malformed block at word %lld (op %lld)",
                 (long long)i, (long long)op);
     int rc = LPG_OK;
@@ -808,11 +808,11 @@ LPG_EXPORT int lpg_twowl_forward_small(const int64_t* block, int64_t n_words, vo
     } else if (op == 7) {
       rc = lpg_tuple_readout_f32(a[0], a[1], a[2], a[3], a[4], wp<const int64_t>(a[5]), wp<const float>(a[6]),
                                  wp<const float>(a[7]), wp<const int32_t>(a[8]), wp<const int32_t>(a[9]), wp<const double>(a[10]),
-                                 a[11], wp<const float>(a[12]), wp<const float>(a[13]), wp<const float>(a[14]), wf(a[15]),
-                                 static_cast<int>(a[16]), wp<const float>(a[17]), wp<const float>(a[18]), wp<const float>(a[19]),
-                                 wf(a[20]), static_cast<int>(a[21]), wp<const float>(a[22]), wp<const float>(a[23]),
-                                 wp<const int64_t>(a[24]), a[25], wp<const float>(a[26]), wp<const float>(a[27]), wp<float>(a[28]),
-                                 wp<int32_t>(a[29]), stream);
+                                 a[11], a[12], wp<const float>(a[13]), wp<const float>(a[14]), wp<const float>(a[15]), wf(a[16]),
+                                 static_cast<int>(a[17]), wp<const float>(a[18]), wp<const float>(a[19]), wp<const float>(a[20]),
+                                 wf(a[21]), static_cast<int>(a[22]), wp<const float>(a[23]), wp<const float>(a[24]),
+                                 wp<const int64_t>(a[25]), a[26], wp<const float>(a[27]), wp<const float>(a[28]), wp<float>(a[29]),
+                                 wp<int32_t>(a[30]), stream);
     } else {
       rc = lpg_small_readout_f32(wp<const float>(a[0]), wp<const float>(a[1]), a[2], a[3], wp<const double>(a[4]),
                                  wp<const float>(a[5]), wp<const float>(a[6]), wp<const float>(a[7]), a[8],

@@ -236,7 +236,7 @@ struct TwLayerArgs {
   const float *w_a, *w_r, *b_a, *b_r;
   float* t_node;         // [n, 2C] = (T_a | T_r), may be null
   float* y_q;            // [Q, 2C]
-  double* part;          // [gridDim.x][2][64]
+  double* part;          // [gridDim.x][2 kinds][2][64]: column sums of the node rows (kind 0) and of the non-member rows (kind 1)
   int64_t ldx, ldax;
   int n_node, Q, C, tile;
 };
@@ -275,7 +275,9 @@ __global__ __launch_bounds__(kTwBlock) void tw_layer_kernel(const TwLayerArgs a)
   const float bias = (side ? a.b_r : a.b_a)[cc];
   // 32-bit element offsets (the entry point checks that every operand has < 2^31 elements): one VGPR per address
   const uint32_t ldx = static_cast<uint32_t>(a.ldx), ldax = static_cast<uint32_t>(a.ldax), C2 = 2u * C;
-  double s1 = 0.0, s2 = 0.0;
+  // column sums of y and y^2, node rows and non-member rows apart: a candidate list sharded over GPUs sums the second kind
+  // across ranks (lpgnn_amd.dist.ShardedTwoWLScorer) while every rank holds all node rows
+  double s1 = 0.0, s2 = 0.0, q1 = 0.0, q2 = 0.0;
   const int ts = a.tile;
   const int nt_node = (a.n_node + ts - 1) / ts, nt_q = (a.Q + ts - 1) / ts;
   const int gw = blockIdx.x * kTwWaves + wv, nw = gridDim.x * kTwWaves;
@@ -383,22 +385,26 @@ __global__ __launch_bounds__(kTwBlock) void tw_layer_kernel(const TwLayerArgs a)
           } else {
             const float y = acc[u] + bias;
             a.y_q[r * C2 + own] = y;
-            s1 += static_cast<double>(y);
-            s2 += static_cast<double>(y) * static_cast<double>(y);
+            q1 += static_cast<double>(y);
+            q2 += static_cast<double>(y) * static_cast<double>(y);
           }
         }
       }
     }
   }
-  sred[wv][0][lane] = s1;
-  sred[wv][1][lane] = s2;
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    const int which = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < kTwWaves; ++k) s += sred[k][which][ln];
-    a.part[(static_cast<int64_t>(blockIdx.x) * 2 + which) * 64 + ln] = s;
+  for (int kind = 0; kind < 2; ++kind) {
+    if (kind) __syncthreads();                               // the first kind's sums have been read
+    sred[wv][0][lane] = kind ? q1 : s1;
+    sred[wv][1][lane] = kind ? q2 : s2;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < kTwWaves; ++k) s += sred[k][which][ln];
+      a.part[((static_cast<int64_t>(blockIdx.x) * 2 + kind) * 2 + which) * 64 + ln] = s;
+    }
   }
 }
 
@@ -675,7 +681,7 @@ LPG_EXPORT int lpg_tuple_apply_f32(int64_t n_node, int64_t Q, int64_t C, const f
 
 LPG_EXPORT int lpg_tuple_readout_f32(int64_t n_node, int64_t Q, int64_t C, int64_t E1, int64_t P, const int64_t* pos_edge,
                                      const float* t_node, const float* y_q, const int32_t* cnt, const int32_t* qpos,
-                                     const double* part, int64_t n_part, const float* gw_a, const float* gb_a,
+                                     const double* part, int64_t n_part, int64_t n_rows, const float* gw_a, const float* gb_a,
                                      const float* gms_a, float eps_a, int relu_a, const float* gw_r, const float* gb_r,
                                      const float* gms_r, float eps_r, int relu_r, const float* b_a, const float* b_r,
                                      const int64_t* idx, int64_t B, const float* w, const float* b0, float* out,
@@ -686,8 +692,8 @@ LPG_EXPORT int lpg_tuple_readout_f32(int64_t n_node, int64_t Q, int64_t C, int64
   LPG_REQUIRE(t_node && cnt && qpos && b_a && b_r && idx && w && out && (E1 == 0 || pos_edge) && (Q == 0 || y_q),
               "tuple_readout: null pointer");
   TwNorm nm;
-  LPG_REQUIRE(make_norm(&nm, part, n_part, P, gw_a, gb_a, gms_a, eps_a, relu_a, gw_r, gb_r, gms_r, eps_r, relu_r),
-              "tuple_readout: 1 <= n_part <= %d partial blocks needed", kTwMaxPart);
+  LPG_REQUIRE(make_norm(&nm, part, n_part, n_rows, gw_a, gb_a, gms_a, eps_a, relu_a, gw_r, gb_r, gms_r, eps_r, relu_r),
+              "tuple_readout: 1 <= n_part <= %d partial blocks and n_rows >= 1 needed", kTwMaxPart);
   LPG_REQUIRE(reinterpret_cast<uintptr_t>(idx) % 16 == 0, "tuple_readout: idx must be 16-byte aligned");
   int ts = 1;
   while (ts < 64 && B > 8192 * ts) ts *= 2;

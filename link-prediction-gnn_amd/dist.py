@@ -494,3 +494,44 @@ class RcclComm:
         if self._comm:
             self._lib.check(self._lib.load().lpg_comm_destroy(self._comm), "comm_destroy")
             self._comm = self._ct.c_void_p()
+
+
+class ShardedTwoWLScorer:
+    """TwoWL scoring with the CANDIDATE tuples sharded across ranks (SURVEY.md section 8e (i) for the 2-WL model): rank g
+    holds a replica of the graph, the model and the node-level tables, and the non-member rows of its own contiguous slice
+    of the candidate pairs.  Unlike SEAL's subgraphs the candidates are not independent: GraphNorm's column statistics
+    run over ALL tuples (TwoWL/model/model.py:38,77 -- Seq passes the whole [P, C] tensor), so every 2-WL layer has one
+    real exchange step: the sums of y and y^2 over the non-member rows, a [2, 64] float64 block, are all-reduced
+    (RCCL over xGMI; 1 KB per layer), the member rows' sums are identical on every rank.  Scores equal the single-GPU
+    forward over the whole candidate list up to the order of those sums.
+
+    pos_edge [2, E1], pred_edge [2, Ep] (both in double()'s layout: a candidate PAIR is two consecutive tuples)."""
+
+    def __init__(self, mod, n_node, pos_edge, pred_edge, group=None, world=None, rank=None):
+        import torch.distributed as dist
+        from . import twowl
+        ready = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if ready else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if ready else 0)
+        self.collective = ready
+        self.mod, self.pos_edge = mod, pos_edge
+        E1, Ep = pos_edge.shape[1], pred_edge.shape[1]
+        if Ep % 2:
+            raise ValueError("ShardedTwoWLScorer: candidate tuples come in pairs (double()'s layout)")
+        self.lo, self.hi = source_range(Ep // 2, self.world, self.rank)          # candidate PAIRS of this rank
+        local = pred_edge[:, 2 * self.lo: 2 * self.hi].contiguous()
+        self.tg = twowl.TupleGraph(n_node, pos_edge, local)
+        self.n_rows = E1 + Ep                                                     # tuples of the whole candidate set
+        self.idx = E1 + torch.arange(local.shape[1], device=pos_edge.device)
+        self.bytes_per_layer = 2 * 64 * 8
+
+    def _reduce(self, block):
+        import torch.distributed as dist
+        if self.collective:
+            dist.all_reduce(block, op=dist.ReduceOp.SUM, group=self.group)
+
+    @torch.no_grad()
+    def __call__(self, x):
+        """x: the degree vector (or node index input) of the model; returns this rank's [hi - lo, 1] logits"""
+        return self.mod.score_tuple_graph(x, self.pos_edge, self.tg, self.idx, reduce_q=self._reduce, n_rows=self.n_rows)

@@ -809,10 +809,11 @@ def tuple_ax_small(plan, x1):
     return x1n, ax
 
 
-def tuple_layer(plan, mode, x, ax, w_a, w_r, b_a, b_r, hq_prev=None, want_t=True):
+def tuple_layer(plan, mode, x, ax, w_a, w_r, b_a, b_r, hq_prev=None, want_t=True, reduce_q=None):
     """one 2-WL layer over a TuplePlan (lpg_tuple_layer_f32).  mode 1: x = the 1-WL output [N, C], ax = A x;
     mode 2: x = (F_a | F_r) [N, 2C], ax = A x, hq_prev [Q, C].
-    -> (t_node [N, 2C] or None, y_q [Q, 2C], part [n_blocks, 2, 64])"""
+    reduce_q: callable(tensor [2, 64] float64) summing it in place over the ranks of a sharded candidate list.
+    -> (t_node [N, 2C] or None, y_q [Q, 2C], part [n_part, 2, 64])"""
     lib = _lib.load()
     xt, ax = _c(x, torch.float32), _c(ax, torch.float32)
     w_a, w_r, b_a, b_r = (_c(v, torch.float32) for v in (w_a, w_r, b_a, b_r))
@@ -827,20 +828,23 @@ def tuple_layer(plan, mode, x, ax, w_a, w_r, b_a, b_r, hq_prev=None, want_t=True
     nb = int(_lib.check(lib.lpg_tuple_layer_blocks(N, Q), "tuple_layer_blocks"))
     t_node = torch.empty((N, 2 * C), dtype=torch.float32, device=dev) if want_t else None
     y_q = torch.empty((max(Q, 1), 2 * C), dtype=torch.float32, device=dev)
-    part = torch.empty((nb, 2, 64), dtype=torch.float64, device=dev)
+    part = torch.empty((2 * nb, 2, 64), dtype=torch.float64, device=dev)     # even blocks: member rows, odd: non-member rows
     hq_prev = _c(hq_prev, torch.float32)
     _lib.keepalive(xt, ax, hq_prev, plan.cnt, plan.qinfo, w_a, w_r, b_a, b_r, t_node, y_q, part)
     _lib.call("lpg_tuple_layer_f32", int(mode), N, Q, C, _ptr(xt), xt.stride(0), _ptr(ax), ax.stride(0), _ptr(hq_prev),
               _ptr(plan.cnt), _ptr(plan.qinfo), _ptr(w_a), _ptr(w_r), _ptr(b_a), _ptr(b_r), _ptr(t_node), _ptr(y_q),
               _ptr(part), nb, _stream())
-    if nb > TUPLE_MAX_PART:                    # big graphs: one more small launch folds the partial sums
-        folded = torch.empty((16, 2, 64), dtype=torch.float64, device=dev)
-        _lib.check(lib.lpg_tuple_fold_f64(_ptr(part), nb, _ptr(folded), 16, _stream()), "tuple_fold")
+    if 2 * nb > TUPLE_MAX_PART or reduce_q is not None:     # big graphs (or sharded candidates): one more small launch folds the partial sums
+        n_out = 2 if reduce_q is not None else 16
+        folded = torch.empty((n_out, 2, 64), dtype=torch.float64, device=dev)
+        _lib.check(lib.lpg_tuple_fold_f64(_ptr(part), 2 * nb, _ptr(folded), n_out, _stream()), "tuple_fold")
         part = folded
+        if reduce_q is not None:
+            reduce_q(part[1])                   # the non-member rows' sums, summed over the ranks that hold the other candidates
     return t_node, y_q, part
 
 
-def tuple_apply(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, b_r):
+def tuple_apply(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, b_r, n_rows=None):
     """GraphNorm (+ ReLU) of a 2-WL layer's two outputs, for the next layer: ff [N, 2C] = (F_a | F_r), hq [Q, C]"""
     lib = _lib.load()
     C = t_node.shape[1] // 2
@@ -848,12 +852,12 @@ def tuple_apply(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, b_
     ff = torch.empty_like(t_node)
     hq = torch.empty((max(plan.Q, 1), C), dtype=torch.float32, device=t_node.device)
     _lib.check(lib.lpg_tuple_apply_f32(plan.n_node, plan.Q, C, _ptr(t_node), _ptr(y_q), _ptr(plan.cnt), _ptr(part),
-                                       part.shape[0], plan.P, *_norm_args(norm_a, relu_a), *_norm_args(norm_r, relu_r),
-                                       _ptr(b_a), _ptr(b_r), _ptr(ff), _ptr(hq), _stream()), "tuple_apply")
+                                       part.shape[0], plan.P if n_rows is None else int(n_rows), *_norm_args(norm_a, relu_a),
+                                       *_norm_args(norm_r, relu_r), _ptr(b_a), _ptr(b_r), _ptr(ff), _ptr(hq), _stream()), "tuple_apply")
     return ff, hq
 
 
-def tuple_readout(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, b_r, idx, w, b0):
+def tuple_readout(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, b_r, idx, w, b0, n_rows=None):
     """TwoWL/model/model.py:78-83 over the last 2-WL layer (GraphNorm + ReLU applied on load) -> [B, 1] logits"""
     C = t_node.shape[1] // 2
     idx = _c(idx.reshape(-1), torch.int64)
@@ -866,7 +870,8 @@ def tuple_readout(plan, t_node, y_q, part, norm_a, relu_a, norm_r, relu_r, b_a, 
     na, nr = _norm_args(norm_a, relu_a), _norm_args(norm_r, relu_r)
     _lib.keepalive(plan.pos_edge, t_node, y_q, plan.cnt, plan.qpos, part, b_a, b_r, idx, w, b0, out)
     _lib.call("lpg_tuple_readout_f32", plan.n_node, plan.Q, C, plan.E1, plan.P, _ptr(plan.pos_edge), _ptr(t_node), _ptr(y_q),
-              _ptr(plan.cnt), _ptr(plan.qpos), _ptr(part), part.shape[0], *na, *nr, _ptr(b_a), _ptr(b_r), _ptr(idx), B,
+              _ptr(plan.cnt), _ptr(plan.qpos), _ptr(part), part.shape[0], plan.P if n_rows is None else int(n_rows), *na, *nr,
+              _ptr(b_a), _ptr(b_r), _ptr(idx), B,
               _ptr(w), _ptr(b0), _ptr(out), _ptr(err_flag(t_node.device)), _stream())
     return out
 

@@ -302,9 +302,18 @@ class LocalWLNet(nn.Module):
         can hold"""
         tp = tg.plan()
         return (len(self.conv2s) == 1 and 0 <= tp.A.max_row <= _ops.TUPLE_AX_SMALL_MAX_ROW
-                and _lib.load().lpg_tuple_layer_blocks(tp.n_node, tp.Q) <= _ops.TUPLE_MAX_PART)
+                and 2 * _lib.load().lpg_tuple_layer_blocks(tp.n_node, tp.Q) <= _ops.TUPLE_MAX_PART)
 
-    def _two_wl_node(self, x1, tg, idx):
+    def score_tuple_graph(self, x, edge1, tg, idx, reduce_q=None, n_rows=None):
+        """the scoring forward over a structured tuple graph with the hooks a sharded candidate list needs
+        (lpgnn_amd.dist.ShardedTwoWLScorer): reduce_q sums the non-member rows' GraphNorm statistics over the ranks,
+        n_rows is the number of tuples of the WHOLE candidate set.  Kernel-per-op 1-WL stage, per-node 2-WL stage."""
+        _forward_only(self)
+        if not tg.plan().ok:
+            raise ValueError("score_tuple_graph: the tuple graph does not meet the layout conditions of the per-node form")
+        return self._two_wl_node(self._one_wl_stage(x, edge1), tg, idx, reduce_q=reduce_q, n_rows=n_rows)
+
+    def _two_wl_node(self, x1, tg, idx, reduce_q=None, n_rows=None):
         """model.py:75-83 without the tuple graph: x1 = the 1-WL output [N, C] (tensor or `Deferred`).  Per 2-WL layer:
         (A x) over the member adjacency (a workgroup per node on the small-graph path, the CSR SpMM otherwise), one
         launch for both orientations' node tables and non-member rows, GraphNorm folded into whichever kernel reads
@@ -325,13 +334,14 @@ class LocalWLNet(nn.Module):
                     if isinstance(x1, _ops.Deferred):
                         x1 = x1.norm(x1.y, relu=x1.relu) if x1.part is not None else x1.y
                     ax = tp.A.spmm(x1, use_val=False)
-                t, yq, part = _ops.tuple_layer(tp, 1, x1, ax, ca.lin.weight, cr.lin.weight, ba, br)
+                t, yq, part = _ops.tuple_layer(tp, 1, x1, ax, ca.lin.weight, cr.lin.weight, ba, br, reduce_q=reduce_q)
             else:
-                ff, hq = _ops.tuple_apply(tp, t, yq, part, *prev)
+                ff, hq = _ops.tuple_apply(tp, t, yq, part, *prev, n_rows=n_rows)
                 aff = tp.A.spmm(ff, use_val=False)
-                t, yq, part = _ops.tuple_layer(tp, 2, ff, aff, ca.lin.weight, cr.lin.weight, ba, br, hq_prev=hq)
+                t, yq, part = _ops.tuple_layer(tp, 2, ff, aff, ca.lin.weight, cr.lin.weight, ba, br, hq_prev=hq,
+                                               reduce_q=reduce_q)
             prev = cur
-        out = _ops.tuple_readout(tp, t, yq, part, *prev, idx, self.pred.weight, self.pred.bias)
+        out = _ops.tuple_readout(tp, t, yq, part, *prev, idx, self.pred.weight, self.pred.bias, n_rows=n_rows)
         _ops.maybe_check(out.device, "LocalWLNet index")
         return out
 

@@ -266,3 +266,51 @@ def test_ranges_cover_and_balance():
     assert ldist.row_blocks(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert ldist.shard_layout(5_000_000, 8, 4) == (625_000, 156_250)
     assert ldist.shard_layout(203, 2, 5) == (105, 21)
+
+
+def _twowl_shard_worker(rank, world, port, q):
+    """two processes on GPU 0 over gloo: dist.ShardedTwoWLScorer against the one-GPU forward over all candidates"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lpgnn_amd import dist as ldist, twowl
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(9)                    # identical on every rank
+    n = 2500
+    pe = twowl.double(torch.randint(0, n, (2, 15_000), generator=g).to(dev))
+    pr = twowl.double(torch.randint(0, n, (2, 777), generator=g).to(dev))
+    xdeg = twowl.degree(pe, n)
+    torch.manual_seed(1)
+    mod = twowl.LocalWLNet(int(xdeg.max()), channels_1wl=24, channels_2wl=16, depth2=3).to(dev).eval()
+    with torch.no_grad():
+        full = mod.score_tuple_graph(xdeg, pe, twowl.tuple_graph(n, pe, pr), pe.shape[1] + torch.arange(pr.shape[1], device=dev))
+    sc = ldist.ShardedTwoWLScorer(mod, n, pe, pr)
+    mine = sc(xdeg)
+    # without the exchange the GraphNorm statistics would cover this rank's candidates only: a different function
+    sc.collective = False
+    alone = sc(xdeg)
+    q.put((rank, float((mine - full[sc.lo:sc.hi]).abs().max()), float((alone - full[sc.lo:sc.hi]).abs().max()),
+           float(full.abs().max()), sc.hi - sc.lo))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_twowl_candidate_sharding_world2_on_the_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_twowl_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sum(r[4] for r in res) == 777
+    for rank, err, err_alone, scale, _ in res:
+        assert err <= 2e-5 * scale, (rank, err, scale)
+        assert err_alone > 10 * err            # the all-reduce of the statistics is what makes the shards agree
+
+
+test_twowl_candidate_sharding_world2_on_the_gpu = __import__("pytest").mark.gpu(test_twowl_candidate_sharding_world2_on_the_gpu)

@@ -75,6 +75,25 @@ def _rccl_worker(rank, world, port, q):
     out["bf16_wire"] = (ok_w, ok_b, prof_ok, opw.bytes_on_links_per_step(d, torch.float32),
                         opb.bytes_on_links_per_step(d, torch.float32))
 
+    # TwoWL with the candidate tuples sharded over the ranks: GraphNorm's statistics over the non-member rows are
+    # all-reduced per 2-WL layer (dist.ShardedTwoWLScorer); this rank's logits == its slice of the one-GPU forward
+    from lpgnn_amd import twowl
+    g2 = torch.Generator().manual_seed(5)
+    n2 = 3000
+    und = torch.randint(0, n2, (2, 20_000), generator=g2)
+    pe = twowl.double(und.to(dev))
+    pr = twowl.double(torch.randint(0, n2, (2, 1001), generator=g2).to(dev))
+    xdeg = twowl.degree(pe, n2)
+    torch.manual_seed(3)
+    mod = twowl.LocalWLNet(int(xdeg.max()), channels_1wl=32, channels_2wl=16, depth2=2).to(dev).eval()
+    tg_all = twowl.tuple_graph(n2, pe, pr)
+    with torch.no_grad():
+        full_logits = mod.score_tuple_graph(xdeg, pe, tg_all, pe.shape[1] + torch.arange(pr.shape[1], device=dev))
+    sc2 = ldist.ShardedTwoWLScorer(mod, n2, pe, pr)
+    mine_logits = sc2(xdeg)
+    out["twowl_sharded"] = (float((mine_logits - full_logits[sc2.lo:sc2.hi]).abs().max()), float(full_logits.abs().max()),
+                            tuple(mine_logits.shape), sc2.hi - sc2.lo)
+
     def score_fn(p):                                      # stands in for the single-GPU SEAL scorer
         return (p[:, 0] * 1000 + p[:, 1]).to(torch.float32)
 
@@ -117,6 +136,8 @@ def _run(world):
             err, scale, used, packed, _ = out[collective]
             assert used == collective and packed == (collective == "sparse")
             assert err <= 1e-5 * (scale + 1.0), (rank, collective, err)
+        err_t, scale_t, shape_t, npairs = out["twowl_sharded"]
+        assert shape_t == (npairs, 1) and err_t <= 2e-5 * scale_t, (rank, err_t, scale_t)
         ok_w, ok_b, prof_ok, bytes_w, bytes_f = out["bf16_wire"]
         assert ok_w and ok_b and prof_ok and bytes_w * 2 == bytes_f and (bytes_f > 0) == (world > 1)
 
