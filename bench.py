@@ -200,7 +200,7 @@ def _time_ms(fn, iters, warm=3):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-def twowl_scaled_bench(device, iters=20, n_pairs=100_000):
+def twowl_scaled_bench(device, iters=20, n_pairs=100_000, shape=(235_868, 1_285_465, 1, "collab")):
     """TwoWL beyond toy graphs: the "ogbl-collab"-shaped stand-in of configs[2] (RMAT |V| = 235 868, 1 285 465
     undirected edges, seed 1 -> 2.57 M directed graph tuples) + 100 K candidate pairs (200 K candidate tuples), model
     defaults C1 = 256, C2 = 32, depth 1/1 (TwoWL/model/model.py:13-16).  The explicit tuple graph of
@@ -208,8 +208,8 @@ def twowl_scaled_bench(device, iters=20, n_pairs=100_000):
     structured handle (twowl.TupleGraph) in its two forms: per-node sums all the way ("node"), and GCNConv per
     orientation on materialised [P, C] rows ("operator": group sums + broadcast, what a module-by-module caller gets)."""
     from lpgnn_amd import ops, twowl
-    N, E, C1, C2 = 235_868, 1_285_465, 256, 32
-    und = rmat_edges(N, E, 1, device)
+    (N, E, seed, label), C1, C2 = shape, 256, 32
+    und = rmat_edges(N, E, seed, device)
     pos_edge = twowl.double(und)
     gen = torch.Generator(device=device)
     gen.manual_seed(2)
@@ -225,12 +225,12 @@ def twowl_scaled_bench(device, iters=20, n_pairs=100_000):
     deg = x_deg.double()
     starts = twowl.degree(torch.stack([pred_edge[1], pred_edge[0]]), N).double() + deg
     e2 = int((deg * starts).sum().item())
-    out = {"workload": f"collab-shaped TwoWL scoring forward fp32: |V|={N}, {E1} graph tuples + {Ep} candidate tuples "
+    out = {"workload": f"{label}-shaped TwoWL scoring forward fp32: |V|={N}, {E1} graph tuples + {Ep} candidate tuples "
                        f"({n_pairs} scored edges), C1={C1} C2={C2} depth 1/1; structured tuple graph (no ei2)",
            "scored_edges": n_pairs, "P": P, "e2_explicit": e2}
     res = {}
     with torch.no_grad():
-        for mode in ("node", "operator"):
+        for mode in (("node", "operator") if label == "collab" else ("node",)):
             twowl._IMPLICIT_MODE = mode
             try:
                 fwd = lambda: mod(x_deg, pos_edge, tg.pos1, idx, tg, True)
@@ -251,7 +251,7 @@ def twowl_scaled_bench(device, iters=20, n_pairs=100_000):
                 ms2 = _time_ms(stage, iters)
                 res[mode] = {"ms_per_forward": ms, "scored_edges_per_s": n_pairs / (ms * 1e-3), "two_wl_stage_ms": ms2,
                              "one_wl_stage_ms": ms - ms2}
-                if mode == "node":
+                if mode == "node" and label == "collab":
                     try:                                     # the same forward replayed from one hipGraph (no launch gaps)
                         cap = twowl.CapturedForward(mod, x_deg, pos_edge, tg.pos1, Ep, tg)
                         assert torch.equal(cap(), ref)
@@ -269,7 +269,7 @@ def twowl_scaled_bench(device, iters=20, n_pairs=100_000):
                     # + indices), node tables and the candidates' rows; everything but the gather is N- or Q-sized
                     alg = E1 * (C2 * 4 + 4) + N * C2 * 4 * 4 + Ep * C2 * 4 * 3
                     res[mode].update({"algorithmic_bytes": alg, "achieved_GBs": alg / (ms2 * 1e-3) / 1e9,
-                                      "bound": "infinity-cache (x1 is 30 MB: the gather never leaves the die)"})
+                                      "bound": f"infinity-cache (x1 is {N * C2 * 4 // 1_000_000} MB: the gather never leaves the die)"})
             except Exception as e:
                 res[mode] = {"error": repr(e)}
             finally:
@@ -937,7 +937,9 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(d)
             if not args.no_twowl:
-                for key, fn in (("twowl", twowl_forward_bench), ("twowl_scaled", twowl_scaled_bench), ("seal", seal_forward_bench),
+                for key, fn in (("twowl", twowl_forward_bench), ("twowl_scaled", twowl_scaled_bench),
+                                ("twowl_ppa", lambda dv: twowl_scaled_bench(dv, iters=10, shape=(576_289, 30_326_273, 3, "ppa"))),
+                                ("seal", seal_forward_bench),
                                 ("seal_ppa", seal_ppa_bench), ("config4_single_gpu", config4_single_gpu_bench)):
                     try:
                         out[key] = fn(device)
@@ -965,6 +967,7 @@ def main():
               "twowl_fb_implicit_eager": ((out.get("twowl") or {}).get("implicit") or {}).get("scored_edges_per_s_eager"),
               "twowl_collab_100k_per_gpu_sharded": (out.get("twowl_sharded") or {}).get("scored_edges_per_s"),
               "twowl_collab_100k": (out.get("twowl_scaled") or {}).get("scored_edges_per_s"),
+              "twowl_ppa_100k": (out.get("twowl_ppa") or {}).get("scored_edges_per_s"),
               "twowl_collab_100k_hipgraph": (lambda m: 100_000 / (m * 1e-3) if isinstance(m, float) else None)(
                   (out.get("twowl_scaled") or {}).get("ms_per_forward_hipgraph")),
               "twowl_collab_100k_operator_form": ((out.get("twowl_scaled") or {}).get("operator_form") or {}).get("scored_edges_per_s")}
