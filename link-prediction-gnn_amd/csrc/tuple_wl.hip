@@ -546,6 +546,34 @@ __global__ __launch_bounds__(kBlock) void tw_bcast_kernel(int64_t P, int C, int 
   }
 }
 
+// the same, four columns per thread (C % 4 == 0, 16-byte aligned rows): one descriptor read and one 16-byte streaming
+// store per piece instead of a 64-bit division, three index loads and a 4-byte store per element (0.24 -> ~0.1 ms for
+// 2.77 M rows x 32)
+__global__ __launch_bounds__(kBlock) void tw_bcast4_kernel(int64_t P, int C4, int orient, const int32_t* __restrict__ tnode,
+                                                           const int32_t* __restrict__ cnt, const int32_t* __restrict__ qpos,
+                                                           const float* __restrict__ t_node, int64_t ldt,
+                                                           const float* __restrict__ hq, int64_t ldh,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int64_t ldy) {
+  const int c4 = threadIdx.x % C4, rin = threadIdx.x / C4, rpb = kBlock / C4;
+  const float4 bi = bias ? *reinterpret_cast<const float4*>(bias + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * rpb + rin; b < P; b += static_cast<int64_t>(gridDim.x) * rpb) {
+    const int node = tnode[2 * b + orient], cn = cnt[node], q = qpos[b];
+    const float4 t = *reinterpret_cast<const float4*>(t_node + static_cast<int64_t>(node) * ldt + 4 * c4);
+    float4 o;
+    if (q < 0) {
+      const float r = __builtin_amdgcn_rcpf(static_cast<float>(cn));
+      o = make_float4(fmaf(t.x, r, bi.x), fmaf(t.y, r, bi.y), fmaf(t.z, r, bi.z), fmaf(t.w, r, bi.w));
+    } else {
+      const float cf = static_cast<float>(cn);
+      const float ca = cn > 0 ? __builtin_amdgcn_rsqf(cf * (cf + 1.0f)) : 0.f, cb = __builtin_amdgcn_rcpf(cf + 1.0f);
+      const float4 h = *reinterpret_cast<const float4*>(hq + static_cast<int64_t>(q) * ldh + 4 * c4);
+      o = make_float4(t.x * ca + h.x * cb + bi.x, t.y * ca + h.y * cb + bi.y, t.z * ca + h.z * cb + bi.z,
+                      t.w * ca + h.w * cb + bi.w);
+    }
+    store_stream(y + b * ldy + 4 * c4, o);
+  }
+}
+
 bool make_norm(TwNorm* nm, const double* part, int64_t n_part, int64_t n_rows, const float* gw_a, const float* gb_a,
                const float* gms_a, float eps_a, int relu_a, const float* gw_r, const float* gb_r, const float* gms_r,
                float eps_r, int relu_r) {
@@ -709,7 +737,14 @@ LPG_EXPORT int lpg_tuple_bcast_f32(int64_t P, int64_t C, int orient, const int32
   LPG_REQUIRE(P >= 0 && C >= 1 && (orient == 0 || orient == 1) && ldt >= C && ldy >= C, "tuple_bcast: bad argument");
   if (P == 0) return LPG_OK;
   LPG_REQUIRE(tnode && cnt && qpos && t_node && y, "tuple_bcast: null pointer");
-  hipLaunchKernelGGL(tw_bcast_kernel, dim3(grid_for(P * C)), dim3(kBlock), 0, as_stream(stream), P, static_cast<int>(C), orient,
-                     tnode, cnt, qpos, t_node, ldt, hq, ldh, bias, y, ldy);
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  const int64_t c4 = C / 4;
+  if (C % 4 == 0 && c4 <= kBlock && kBlock % c4 == 0 && ldt % 4 == 0 && ldy % 4 == 0 && (!hq || ldh % 4 == 0) && al16(t_node) &&
+      al16(y) && (!hq || al16(hq)) && (!bias || al16(bias)))
+    hipLaunchKernelGGL(tw_bcast4_kernel, dim3(grid_for(P * c4)), dim3(kBlock), 0, as_stream(stream), P, static_cast<int>(c4),
+                       orient, tnode, cnt, qpos, t_node, ldt, hq, ldh, bias, y, ldy);
+  else
+    hipLaunchKernelGGL(tw_bcast_kernel, dim3(grid_for(P * C)), dim3(kBlock), 0, as_stream(stream), P, static_cast<int>(C), orient,
+                       tnode, cnt, qpos, t_node, ldt, hq, ldh, bias, y, ldy);
   return check_launch("tuple_bcast");
 }
