@@ -51,7 +51,7 @@ int lpg_abi_version(void);
  * their edge-less rows on a library-owned second stream beside the main kernel, joined before the call's work on the
  * caller's stream ends; never inside a stream capture), "seal_conv_fp32", "gn_small",
  * "seal_conv_variant", "linear_percu_delta", "linear_wres" (-1 automatic, 0 off, 1..3 force a W-resident variant),
- * "linear_x3" (-1 automatic, 0 off, 1 force: the fp32 linear as exact three-plane bf16 products, csrc/linear_x3.hip), "seal_pair_small",
+ * "linear_x3" (-1 automatic, 0 off, 1 force the strip form / 2 the tiled form of the fp32 linear as exact three-plane bf16 products, csrc/linear_x3.hip), "seal_pair_small",
  * "spmm_phase_timing" (1: lpg_csr_spmm_* record events around their kernels, see lpg_csr_spmm_phase_ms).
  * `name` is a HOST string.  set: 0 / LPG_E_INVALID (unknown name, value out of range); get: the value, INT64_MIN
  * for an unknown name.  lpg_tuning_build() = 1 for a -DLPG_TUNING build (profiles/ sweeps only: seeds the table

@@ -285,6 +285,191 @@ __global__ __launch_bounds__(kBlockX3) void linear_x3_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The tiled form (r03), for k % 32 == 0, m % 128 == 0 and W stored [m][k].
+//
+// What bounded the kernel above at 256 -> 256 (1.72 ms for 2 M rows = 0.30 of HBM; MFMA work at peak: 0.63 ms) is VALU
+// ISSUE, not the matrix cores: a wave splits every X fragment it multiplies itself, W is cut into FOUR strips of 64
+// columns at k = 256 (three planes of a wider strip do not fit the LDS), so every element of X is split four times
+// and a 32-k group costs ~200 VALU instructions (ISA count: ~110 of split + 40 of moves around the ragged-k select +
+// addressing) beside its 48 MFMAs of 16 cycles: 800 issue cycles against 768 matrix cycles, with two waves per SIMD.
+//
+// Here a 256-thread workgroup owns a 128 x 128 output tile and walks k in chunks of 32: the chunk of X (128 rows) and of W
+// (128 columns) is loaded to registers one chunk ahead, split ONCE by the thread that loaded it (9 instructions per
+// pair of values: v_perm packs the high halves, v_pk_add_f32 forms both remainders) and stored as three bf16 planes
+// in LDS in the fragment order of v_mfma_f32_16x16x32_bf16 (48 KB per workgroup, three workgroups per CU, whose load /
+// split / multiply phases interleave on the SIMDs); each of the four waves multiplies a 64 x 64 sub-tile: 24 LDS
+// fragment reads and 96 MFMAs per chunk, and ~150 VALU instructions of split per thread per chunk against those 96
+// MFMAs -- a quarter of the ratio above.  X is read from HBM once (the strips of a row tile run side by side on one
+// XCD and share it through that XCD's L2), W (256 KB) stays in L2.
+//
+// Measured (profiles/r03/linear_x3_tiled.log, same box, 2 M rows 256 -> 256 / 5 M rows 128 -> 128): strip form 1.60 / 1.19 ms,
+// this form 1.55 / 1.19 ms, and 0.018 against 0.029 ms at 50 K rows (no W staging per workgroup).  Three designs -- the
+// strip form, this one, and this one on v_mfma_f32_32x32x16_bf16 (half the MFMA issues: 1.70 / 1.32 ms, slower: the chip
+// holds a lower clock on that shape, MI355X guide 'DVFS give-back' (7)) -- all stop at ~1.0 PF of bf16 MFMA on random
+// data: the six-product sum is bound by the matrix cores at the clock they sustain under load (the guide's best bf16
+// GEMM body: 1.25 PF), i.e. 1.26 ms for this shape = 0.41 of the HBM time at best.  A persistent grid with cross-tile
+// prefetch was slower (1.84 ms at two workgroups per CU; three do not fit without scratch).
+constexpr int kTileR = 128, kTileC = 128;
+constexpr int kBlockT = 256;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// two values -> their three bf16 terms, packed (first value in the low half)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& H, uint32_t& M, uint32_t& L) {
+  constexpr uint32_t kHiHalves = 0x07060302u;             // v_perm_b32: (bytes 3:2 of src0) : (bytes 3:2 of src1)
+  const uint32_t a0 = __float_as_uint(a), b0 = __float_as_uint(b);
+  H = __builtin_amdgcn_perm(b0, a0, kHiHalves);
+  const f32x2 v = {a, b};
+  const f32x2 t = {__uint_as_float(a0 & 0xFFFF0000u), __uint_as_float(b0 & 0xFFFF0000u)};
+  const f32x2 r = v - t;
+  const uint32_t a1 = __float_as_uint(r.x), b1 = __float_as_uint(r.y);
+  M = __builtin_amdgcn_perm(b1, a1, kHiHalves);
+  const f32x2 u = {__uint_as_float(a1 & 0xFFFF0000u), __uint_as_float(b1 & 0xFFFF0000u)};
+  const f32x2 q = r - u;                                  // <= 8 significant bits each: already bf16 numbers
+  L = __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), kHiHalves);
+}
+
+__device__ __forceinline__ void split_octet(const float4& a, const float4& b, uint4& H, uint4& M, uint4& L) {
+  split_pair(a.x, a.y, H.x, M.x, L.x);
+  split_pair(a.z, a.w, H.y, M.y, L.y);
+  split_pair(b.x, b.y, H.z, M.z, L.z);
+  split_pair(b.z, b.w, H.w, M.w, L.w);
+}
+
+__global__ __launch_bounds__(kBlockT, 3) void linear_x3t_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ bias, int act,
+                                                                float* __restrict__ y, int64_t ldy, int64_t n, int k,
+                                                                int strips, int64_t n_rtiles) {
+  // a plane of a chunk is [4 k octets][128 rows or columns][8 k] bf16: lane (c, g) of a fragment read takes the 16-byte
+  // slot (g, base + c); the 16 lanes of a group read 256 contiguous bytes
+  __shared__ uint4 xs[3][4][kTileR];
+  __shared__ uint4 ws[3][4][kTileC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;                // the wave's 64 x 64 quarter of the tile
+  // workgroup v sits on XCD v % 8: the strips of one row tile are neighbours in that XCD's dispatch order.  (A
+  // persistent grid that prefetches the next tile's first chunk during the last chunk of this one measured SLOWER:
+  // 1.84 ms against 1.71 at two workgroups per CU, and does not fit three per CU without scratch.)
+  const int v = blockIdx.x, xcd = v & 7, slot = v >> 3;
+  const int strip = slot % strips;
+  const int64_t rtile = static_cast<int64_t>(slot / strips) * 8 + xcd;
+  if (rtile >= n_rtiles) return;                          // whole workgroup: no barrier is skipped
+  const int64_t r0 = rtile * kTileR;
+  const int j0 = strip * kTileC;
+
+  // loader role: thread (lr, lo) takes k octet lo of rows lr and lr + 64 of X and of columns lr and lr + 64 of W: the
+  // four lanes of a row read one 128-byte line per chunk
+  const int lr = tid >> 2, lo = tid & 3;
+  const float* px0 = x + min(r0 + lr, n - 1) * ldx + lo * 8;
+  const float* px1 = x + min(r0 + lr + 64, n - 1) * ldx + lo * 8;
+  const float* pw0 = w + static_cast<int64_t>(j0 + lr) * k + lo * 8;
+  const float* pw1 = w + static_cast<int64_t>(j0 + lr + 64) * k + lo * 8;
+  float4 bx[4], bw[4];
+  auto fetch = [&](int kc) {
+    const int o = kc * 32;
+    bx[0] = *reinterpret_cast<const float4*>(px0 + o);
+    bx[1] = *reinterpret_cast<const float4*>(px0 + o + 4);
+    bx[2] = *reinterpret_cast<const float4*>(px1 + o);
+    bx[3] = *reinterpret_cast<const float4*>(px1 + o + 4);
+    bw[0] = *reinterpret_cast<const float4*>(pw0 + o);
+    bw[1] = *reinterpret_cast<const float4*>(pw0 + o + 4);
+    bw[2] = *reinterpret_cast<const float4*>(pw1 + o);
+    bw[3] = *reinterpret_cast<const float4*>(pw1 + o + 4);
+  };
+  auto stage = [&]() {
+    uint4 H, M, L;
+    split_octet(bx[0], bx[1], H, M, L);
+    xs[0][lo][lr] = H, xs[1][lo][lr] = M, xs[2][lo][lr] = L;
+    split_octet(bx[2], bx[3], H, M, L);
+    xs[0][lo][lr + 64] = H, xs[1][lo][lr + 64] = M, xs[2][lo][lr + 64] = L;
+    split_octet(bw[0], bw[1], H, M, L);
+    ws[0][lo][lr] = H, ws[1][lo][lr] = M, ws[2][lo][lr] = L;
+    split_octet(bw[2], bw[3], H, M, L);
+    ws[0][lo][lr + 64] = H, ws[1][lo][lr + 64] = M, ws[2][lo][lr + 64] = L;
+  };
+
+  const int chunks = k >> 5;
+  f32x4 acc[4][4];                                        // [row tile of 16][column tile of 16]
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[rt][ct][i] = 0.f;
+
+  fetch(0);
+  for (int kc = 0; kc < chunks; ++kc) {
+    if (kc) __syncthreads();                              // every wave is done with the previous chunk's planes
+    stage();
+    __syncthreads();
+    if (kc + 1 < chunks) fetch(kc + 1);                   // in flight while this chunk is multiplied
+    bf16x8 wf[3][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) wf[p][ct] = __builtin_bit_cast(bf16x8, ws[p][g][wc * 64 + ct * 16 + c]);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, xs[0][g][wr * 64 + rt * 16 + c]);
+      const bf16x8 xm = __builtin_bit_cast(bf16x8, xs[1][g][wr * 64 + rt * 16 + c]);
+      const bf16x8 xl = __builtin_bit_cast(bf16x8, xs[2][g][wr * 64 + rt * 16 + c]);
+      // small terms first; A = W (rows = output columns), B = X (columns = rows of X); consecutive MFMAs go to
+      // different accumulators
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][ct], xh, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ct], xl, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ct], xm, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ct], xh, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ct], xm, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ct], xh, acc[rt][ct], 0, 0, 0);
+    }
+  }
+
+  // lane (c, g): row c of a row tile; the 4 registers of column tile ct = output columns ct * 16 + 4 g .. + 3
+  auto put = [&](auto fn) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int64_t row = r0 + wr * 64 + rt * 16 + c;
+      if (row < n) {
+        const int col = j0 + wc * 64 + 4 * g;
+        float* yr = y + row * ldy + col;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bias) bb = *reinterpret_cast<const float4*>(bias + col + ct * 16);
+          float4 o;
+          o.x = fn(acc[rt][ct][0] + bb.x);
+          o.y = fn(acc[rt][ct][1] + bb.y);
+          o.z = fn(acc[rt][ct][2] + bb.z);
+          o.w = fn(acc[rt][ct][3] + bb.w);
+          *reinterpret_cast<float4*>(yr + ct * 16) = o;
+        }
+      }
+    }
+  };
+  if (act == LPG_ACT_NONE) put([](float a) { return a; });
+  else if (act == LPG_ACT_RELU) put([](float a) { return fmaxf(a, 0.f); });
+  else put([act](float a) { return apply_act(a, act); });
+}
+
+int launch_x3t(const float* x, int64_t ldx, const float* w, const float* bias, int act, float* y, int64_t ldy, int64_t n, int k,
+               int m, int cus, hipStream_t st) {
+  const int strips = m / kTileC;
+  const int64_t n_rtiles = ceil_div(n, kTileR);
+  (void)cus;
+  const int64_t g = align_up(n_rtiles, 8) * strips;       // row tile = 8 * (slot / strips) + XCD: whole groups of 8
+  if (g > 0x7fffffff) return 0;
+  hipLaunchKernelGGL(linear_x3t_kernel, dim3(static_cast<unsigned>(g)), dim3(kBlockT), 0, st, x, ldx, w, bias, act, y, ldy, n,
+                     k, strips, n_rtiles);
+  return 1;
+}
+
 template <int NT>
 int launch_x3(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, int act, float* y, int64_t ldy,
               int64_t n, int k, int m, int kpad, int cus, int dev, hipStream_t st) {
@@ -316,10 +501,25 @@ namespace lpg {
 // return 1 = launched, 0 = shape does not qualify (the caller goes on to the fp32-MFMA kernels), < 0 = error
 int linear_x3_f32(const float* x, int64_t ldx, const float* w, int w_is_km, const float* bias, int act, float* y,
                   int64_t ldy, int64_t n, int64_t k, int64_t m, hipStream_t st) {
-  const int64_t mode = options().linear_x3;               // -1 automatic; 0 off; 1 force wherever the layout allows
+  const int64_t mode = options().linear_x3;               // -1 automatic; 0 off; 1 force the strip form wherever the layout allows; 2 the tiled form (or nothing)
   if (mode == 0 || n < 1) return 0;
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   if (k % 4 != 0 || m % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || !al16(x) || !al16(y) || k > 768 || ldx < k) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevX3) return 0;
+  static int cus_of[kMaxDevX3] = {};
+  if (!cus_of[dev] &&
+      (hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_of[dev] <= 0))
+    cus_of[dev] = 256;
+  const int cus = cus_of[dev];
+  // the tiled form: k % 32 == 0, m % 128 == 0, W [m][k] 16-byte aligned, bias (if any) 16-byte aligned
+  const bool tiled_ok = !w_is_km && k % 32 == 0 && m % kTileC == 0 && al16(w) && (!bias || al16(bias)) && k >= 32;
+  if (tiled_ok && (mode == 2 || (mode < 0 && options().linear_wres <= 0 && n >= 16384))) {
+    const int rc = launch_x3t(x, ldx, w, bias, act, y, ldy, n, static_cast<int>(k), static_cast<int>(m), cus, st);
+    if (rc == 1) ++options_mut().stat_linear_x3;
+    if (rc != 0) return rc;
+  }
+  if (mode == 2) return 0;
   const int kpad = static_cast<int>(align_up(k, 32));
   int nt = m <= 32 ? 1 : (m <= 64 ? 2 : 4);
   auto lds_of = [&](int t) { return static_cast<size_t>(3) * t * 32 * kpad * 2 + t * 32 * 4; };
@@ -335,13 +535,6 @@ int linear_x3_f32(const float* x, int64_t ldx, const float* w, int w_is_km, cons
     if ((k * m) / (2 * (k + m)) < 20) return 0;
     if (n < (k * m > 128 * 128 ? 16384 : 57344)) return 0;
   }
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevX3) return 0;
-  static int cus_of[kMaxDevX3] = {};
-  if (!cus_of[dev] &&
-      (hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_of[dev] <= 0))
-    cus_of[dev] = 256;
-  const int cus = cus_of[dev];
   const int ki = static_cast<int>(k), mi = static_cast<int>(m);
   int rc;
   if (nt == 1) rc = launch_x3<1>(x, ldx, w, w_is_km, bias, act, y, ldy, n, ki, mi, kpad, cus, dev, st);

@@ -37,7 +37,7 @@ struct Options {
   int64_t linear_wres = -1;      // -1 automatic; 0 off; 1 / 2 / 3 force that W-resident variant (also below n_min)
   int64_t spmm_phase_timing = 0; // 1: record events around the SpMM's kernels (lpg_csr_spmm_phase_ms)
   int64_t seal_pair_small = 1;   // 0: every candidate pair takes the 128-thread extraction workgroup
-  int64_t linear_x3 = -1;        // -1 automatic; 0 off; 1 force: fp32 linear as exact bf16 plane products on the bf16 matrix cores (linear_x3.hip)
+  int64_t linear_x3 = -1;        // -1 automatic; 0 off; 1 force the strip form, 2 the tiled form: fp32 linear as exact bf16 plane products on the bf16 matrix cores (linear_x3.hip)
   int64_t stat_linear_x3 = 0;    // statistic: launches of that kernel so far
   int64_t stat_linear_wres = 0;  // statistic: W-resident linear launches so far (tests assert the path taken; set 0 to reset)
 };

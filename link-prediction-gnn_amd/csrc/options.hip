@@ -38,7 +38,7 @@ const Entry kEntries[] = {
     {"linear_wres", &Options::linear_wres, -1, 3},
     {"spmm_phase_timing", &Options::spmm_phase_timing, 0, 1},
     {"seal_pair_small", &Options::seal_pair_small, 0, 1},
-    {"linear_x3", &Options::linear_x3, -1, 1},
+    {"linear_x3", &Options::linear_x3, -1, 2},
     {"stat_linear_x3", &Options::stat_linear_x3, 0, int64_t(1) << 62},
     {"stat_linear_wres", &Options::stat_linear_wres, 0, int64_t(1) << 62},
 };

@@ -9,6 +9,7 @@ cd $ROOT
 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err
 echo "[collect] bench done"
 python profiles/twowl_scaled.py > $OUT/twowl_scaled.log 2>&1
+python profiles/twowl_ppa.py > $OUT/twowl_ppa.log 2>&1
 python profiles/seal_refmix.py > $OUT/seal_refmix.log 2>&1
 python profiles/seal_stages.py > $OUT/seal_stages.log 2>&1
 python profiles/seal_extract_probe.py > $OUT/seal_extract_by_size.log 2>&1
@@ -16,6 +17,7 @@ LPG_LIB_VARIANT=tuning python profiles/seal_phases.py > $OUT/seal_phases.log 2>&
 python profiles/spmm_mid_graph.py > $OUT/spmm_mid_graph.log 2>&1
 python profiles/degree_ones_probe.py > $OUT/degree_ones_probe.log 2>&1
 python profiles/kernel_zoo.py > $OUT/kernel_zoo.log 2>&1
+python profiles/linear_x3_tiled.py > $OUT/linear_x3_tiled.log 2>&1
 echo "[collect] scripts done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $ROOT/bench.py > $OUT/bench_under_rocprof.log 2>&1

@@ -35,7 +35,8 @@ for n, k, m, km, act in shapes:
     if act: ref = ref.relu()
     mag = x[rows].double().abs() @ wd.abs()
     out = {}
-    for mode in (0, 1):
+    tiled = (not km) and k % 32 == 0 and m % 128 == 0
+    for mode in ((0, 1, 2) if tiled else (0, 1)):
         with _lib.options(linear_x3=mode):
             y = ops.linear(x, w, bias, w_is_km=km, act=act)
             err = float(((y[rows].double() - ref).abs() / mag).max())
@@ -44,6 +45,7 @@ for n, k, m, km, act in shapes:
         del y
     flops = 2 * n * k * m
     print(f"n={n} k={k} m={m} km={km} act={act}: fp32 MFMA {out[0][0]:.3f} ms ({flops / out[0][0] / 1e9:.0f} TF) err/mag {out[0][1]:.1e} | "
-          f"bf16 planes {out[1][0]:.3f} ms ({flops / out[1][0] / 1e9:.0f} TF-equiv, {(n * (k + m) * 4) / out[1][0] / 1e9:.2f} TB/s) err/mag {out[1][1]:.1e}",
+          f"bf16 planes {out[1][0]:.3f} ms ({flops / out[1][0] / 1e9:.0f} TF-equiv, {(n * (k + m) * 4) / out[1][0] / 1e9:.2f} TB/s) err/mag {out[1][1]:.1e}"
+          + (f" | tiled {out[2][0]:.3f} ms ({(n * (k + m) * 4) / out[2][0] / 1e9:.2f} TB/s) err/mag {out[2][1]:.1e}" if tiled else ""),
           flush=True)
     del x

@@ -1825,6 +1825,47 @@ def test_linear_f32_on_bf16_planes(dev, lpg_options, n, k, m, ldx, km, act, bias
     assert np.all(np.abs(_np(off).astype(np.float64) - want) <= TOL * (mag + 1.0))
 
 
+@pytest.mark.parametrize("n,k,m,ldx,act,bias", [
+    (20011, 256, 256, 256, None, False),                 # config 5's dense update, ragged last row tile
+    (20011, 128, 128, 160, "relu", True),                # padded rows of X
+    (4099, 64, 384, 64, "tanh", True),                   # three strips, two chunks
+    (129, 32, 128, 32, None, True),                      # one chunk; the second row tile holds a single row
+])
+def test_linear_f32_on_bf16_planes_tiled(dev, lpg_options, n, k, m, ldx, act, bias):
+    """the tiled form of the bf16-plane linear (linear_x3 = 2: 128 x 128 output tiles, X and W split once per chunk into
+    LDS planes), same bound as the strip form above; rows beyond n are neither read past the buffer nor written."""
+    from lpgnn_amd import _lib, ops
+    lpg_options(linear_x3=2, stat_linear_x3=0)
+    rng = np.random.default_rng(n + k + m)
+    xb = torch.from_numpy(rng.standard_normal((n, ldx)).astype(np.float32)).to(dev)
+    xb[:7, :k] = torch.tensor([1.0, -2.0 ** -20, 16777215.0, -1.9999999, 3.0e-30, 2.0 ** 40, 0.0], device=dev)[:, None]
+    if ldx > k:
+        xb[:, k:] = float("nan")
+    xt = xb[:, :k]
+    wt = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float32)).to(dev)
+    b = rng.standard_normal(m).astype(np.float32) if bias else None
+    x64, w64 = _np(xt).astype(np.float64), _np(wt).astype(np.float64).T
+    want = x64 @ w64 + (b if bias else 0.0)
+    mag = np.abs(x64) @ np.abs(w64) + (np.abs(b) if bias else 0.0)
+    bt = None if b is None else torch.from_numpy(b).to(dev)
+    wide = torch.full((n + 1, m + 8), 7.0, device=dev)
+    ops.linear(xt, wt, bt, act=act, out=wide[:n, :m])
+    assert _lib.get_option("stat_linear_x3") == 1, "not the kernel this test is about"
+    got = _np(wide[:n, :m]).astype(np.float64)
+    if act == "relu":
+        want = np.maximum(want, 0)
+    elif act == "tanh":
+        want = np.tanh(want)
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - want) <= TOL * (mag + 1.0))
+    assert torch.equal(wide[:, m:], torch.full((n + 1, 8), 7.0, device=dev)) and bool((wide[n] == 7.0).all())
+    # W stored [k][m] is not this kernel's layout: forced, the call falls through to the fp32-MFMA kernels
+    lpg_options(linear_x3=2, stat_linear_x3=0)
+    off = ops.linear(xt, wt.t().contiguous(), bt, w_is_km=True, act=act)
+    assert _lib.get_option("stat_linear_x3") == 0
+    assert np.all(np.abs(_np(off).astype(np.float64) - want) <= TOL * (mag + 1.0))
+
+
 @pytest.mark.parametrize("variant", ["auto", "1", "2", "3"])
 @pytest.mark.parametrize("dtype,n,k,m,ldx,km,act,bias", [
     ("f32", 20011, 128, 128, 128, False, None, True),       # MFMA-bound shape, ragged last tile
