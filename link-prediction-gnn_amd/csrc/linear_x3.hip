@@ -310,6 +310,10 @@ __global__ __launch_bounds__(kBlockX3) void linear_x3_kernel(const float* __rest
 // data: the six-product sum is bound by the matrix cores at the clock they sustain under load (the guide's best bf16
 // GEMM body: 1.25 PF), i.e. 1.26 ms for this shape = 0.41 of the HBM time at best.  A persistent grid with cross-tile
 // prefetch was slower (1.84 ms at two workgroups per CU; three do not fit without scratch).
+// Counters of this form (profiles/r03/pmc_x3t_summary.txt): clock 1.96 GHz (GRBM_GUI_ACTIVE / 8 / wall), matrix cores busy
+// 48 % of those cycles (SQ_VALU_MFMA_BUSY_CYCLES = 96 M MFMAs x 16), no LDS bank conflicts; with X confined to an
+// 8 MB footprint (every row tile reading the same 64 tiles: a measurement build) 1.42 / 1.04 ms -- memory latency is
+// worth 10-15 %, a second chunk of prefetch does not fit 168 registers.
 constexpr int kTileR = 128, kTileC = 128;
 constexpr int kBlockT = 256;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -358,9 +362,12 @@ __global__ __launch_bounds__(kBlockT, 3) void linear_x3t_kernel(const float* __r
   const int64_t r0 = rtile * kTileR;
   const int j0 = strip * kTileC;
 
-  // loader role: thread (lr, lo) takes k octet lo of rows lr and lr + 64 of X and of columns lr and lr + 64 of W: the
-  // four lanes of a row read one 128-byte line per chunk
-  const int lr = tid >> 2, lo = tid & 3;
+  // loader role: thread (lr, lo) takes k octet lo of rows lr and lr + 64 of X and of columns lr and lr + 64 of W.  A wave
+  // covers 16 rows: its four 16-lane groups are the four octets of the same rows, so one load instruction consumes 16
+  // whole 128-byte lines, and each 16-lane group of a ds_write_b128 fills 16 CONSECUTIVE slots of one octet row
+  // (lo = tid & 3 put the four octets of a row, 2 KB apart, on the same banks: SQ_LDS_BANK_CONFLICT 2.9e8 cycles per
+  // launch, a third of the kernel)
+  const int lr = (wave << 4) | (lane & 15), lo = lane >> 4;
   const float* px0 = x + min(r0 + lr, n - 1) * ldx + lo * 8;
   const float* px1 = x + min(r0 + lr + 64, n - 1) * ldx + lo * 8;
   const float* pw0 = w + static_cast<int64_t>(j0 + lr) * k + lo * 8;
