@@ -363,7 +363,8 @@ int lpg_compact_cols_i64(const int64_t* in, int64_t rows, int64_t E, const uint8
  *   sharded over GPUs and `part` holds the sums over all ranks' candidates).
  * lpg_tuple_bcast_f32: the broadcast of the operator form -- GCNConv(x, orientation) for an arbitrary [P, C] input:
  *   y[b] = t_node[node(b)] / cnt + bias (member), t_node[node(b)] / sqrt(cnt (cnt + 1)) + hq[q] / (cnt + 1) + bias
- *   (otherwise); t_node = (group sums of x over the members) W^T, hq = x[non-members] W^T. */
+ *   (otherwise); t_node = (group sums of x over the members) W^T, hq = x[non-members] W^T (required whenever any
+ *   qpos >= 0; NULL is only valid for a plan without non-member tuples). */
 int64_t lpg_tuple_plan_bytes(int64_t P);
 int lpg_tuple_plan_build(const int64_t* pos_edge, int64_t E1, const int64_t* pred_edge, int64_t Ep,
                          int64_t n_node, const uint8_t* blocked, const int64_t* rowptr, int32_t* cnt,

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kBlock) void tw_bcast_kernel(int64_t P, int C, int 
     } else {
       const float cf = static_cast<float>(cn);
       o = (cn > 0 ? t * __builtin_amdgcn_rsqf(cf * (cf + 1.0f)) : 0.f) +
-          hq[static_cast<int64_t>(q) * ldh + c] * __builtin_amdgcn_rcpf(cf + 1.0f) + bi;
+          (hq ? hq[static_cast<int64_t>(q) * ldh + c] : 0.f) * __builtin_amdgcn_rcpf(cf + 1.0f) + bi;   // hq == NULL with non-member rows is a caller error (header): no fault, the self term is dropped
     }
     y[b * ldy + c] = o;
   }
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void tw_bcast4_kernel(int64_t P, int C4, in
     } else {
       const float cf = static_cast<float>(cn);
       const float ca = cn > 0 ? __builtin_amdgcn_rsqf(cf * (cf + 1.0f)) : 0.f, cb = __builtin_amdgcn_rcpf(cf + 1.0f);
-      const float4 h = *reinterpret_cast<const float4*>(hq + static_cast<int64_t>(q) * ldh + 4 * c4);
+      const float4 h = hq ? *reinterpret_cast<const float4*>(hq + static_cast<int64_t>(q) * ldh + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
       o = make_float4(t.x * ca + h.x * cb + bi.x, t.y * ca + h.y * cb + bi.y, t.z * ca + h.z * cb + bi.z,
                       t.w * ca + h.w * cb + bi.w);
     }
