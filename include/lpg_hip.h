@@ -63,6 +63,12 @@ int lpg_tuning_build(void);
 /* edges per work chunk the chunked SpMM uses for a graph of capacity e_cap (16..512; tests use it
  * to place rows on chunk borders) */
 int lpg_spmm_chunk_edges(int64_t e_cap);
+/* the association order of the chunked SpMM's fix-up, for a same-order reference loop (oracle/spmm_ref.c): a row whose
+ * per-chunk pieces after the first number more than lpg_spmm_fixup_long_row() is summed as `groups` interleaved
+ * left-to-right sub-sums (piece j goes to sub-sum j % groups) folded by a balanced binary tree, then added to the first
+ * piece; shorter rows are summed left to right.  wide = d, ldx, ldy multiples of 16 bytes and x, y 16-byte aligned. */
+int lpg_spmm_fixup_groups(int64_t d, int elem_bytes, int wide);
+int lpg_spmm_fixup_long_row(void);
 
 /* ---------------------------------------------------------------- scatter_add (K1, K2)
  * torch_scatter.scatter_add(src, index, dim=0, out=None, dim_size=N)   [TwoWL/utils.py:5,10]

@@ -627,47 +627,102 @@ __global__ __launch_bounds__(kBlock) void spmm_edge_kernel(const SpmmArgs a) {
   }
 }
 
+constexpr int kFixupLongRow = 64;   // pieces after the first beyond which a row's fix-up is shared by the wave's groups
+
 // ---- fix-up: finish the rows that straddle chunk borders --------------------------------------
+// The group that owns a row's LAST chunk adds the row's partial sums (carry slots) in chunk order.  A row of more than
+// kLongRow chunks (a hub: thousands of partials) is not walked by its 1..16 lanes alone: every group of the wave takes
+// every GPW-th partial and the groups' sums are folded by shuffles (fixed order).  On the collab-shaped graph (d = 32)
+// the one-group walk was 16 of the fix-up's 18 us.
 template <typename T, int VEC, int G>
 __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
   constexpr int GPW = kWave / G;
+  constexpr int kLongRow = kFixupLongRow;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int64_t wave = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int kChunk = a.chunk;
   const int64_t E = a.rowptr[a.N];
-  if (wave * GPW * kChunk >= E) return;
+  if (wave * GPW * kChunk >= E) return;             // wave-uniform
   const int64_t chunk = wave * GPW + lane / G;
   const int64_t start = chunk * kChunk;
   const int64_t c0 = static_cast<int64_t>(blockIdx.y) * (G * VEC) + gl * VEC;
-  if (start >= E || start == 0 || c0 >= a.d) return;
-  const int r0 = a.rowid[start];
-  if (a.rowid[start - 1] != r0) return;             // first segment starts here: nothing pending
-  const int64_t end = start + kChunk;
-  if (end < E && a.rowid[end] == r0) return;        // row continues: a later chunk finishes it
-  const int64_t first = a.rowptr[r0] / kChunk;      // chunk holding the row's first edge
+  const bool cols = c0 < a.d;                        // this lane's columns exist
+  bool active = start < E && start != 0;
+  int r0 = 0;
+  int64_t first = 0;
+  if (active) {
+    r0 = a.rowid[start];
+    if (a.rowid[start - 1] != r0) active = false;    // first segment starts here: nothing pending
+  }
+  if (active) {
+    const int64_t end = start + kChunk;
+    if (end < E && a.rowid[end] == r0) active = false;   // row continues: a later chunk finishes it
+  }
+  if (active) first = a.rowptr[r0] / kChunk;         // chunk holding the row's first edge
+  const bool lng = GPW > 1 && active && chunk - first > kLongRow;
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  carry_add<VEC>(a.carry + (2 * first + 1) * a.dpad + c0, acc);
   const float* p = a.carry + c0;
-  int64_t c = first + 1;
   constexpr int FU = VEC >= 4 ? 16 : 8;             // partial rows in flight (a star row is a 40 K-long chain)
-  for (; c + FU <= chunk + 1; c += FU) {             // loaded together, added in chunk order
-    float t[FU][VEC];
+  if (active && cols) {
+    carry_add<VEC>(a.carry + (2 * first + 1) * a.dpad + c0, acc);
+    if (!lng) {
+      int64_t c = first + 1;
+      for (; c + FU <= chunk + 1; c += FU) {         // loaded together, added in chunk order
+        float t[FU][VEC];
 #pragma unroll
-    for (int u = 0; u < FU; ++u) {
+        for (int u = 0; u < FU; ++u) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) t[u][i] = 0.f;
-      carry_add<VEC>(p + 2 * (c + u) * a.dpad, t[u]);
+          for (int i = 0; i < VEC; ++i) t[u][i] = 0.f;
+          carry_add<VEC>(p + 2 * (c + u) * a.dpad, t[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += t[u][i];
+      }
+      for (; c <= chunk; ++c) carry_add<VEC>(p + 2 * c * a.dpad, acc);
     }
-#pragma unroll
-    for (int u = 0; u < FU; ++u)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] += t[u][i];
   }
-  for (; c <= chunk; ++c) carry_add<VEC>(p + 2 * c * a.dpad, acc);
-  store_out<T, VEC>(a, r0, c0, acc);
+  if constexpr (GPW > 1) {
+    uint64_t todo = __ballot(lng);                   // every lane of a long group has its bit set
+    while (todo) {                                   // wave-uniform
+      const int src = __builtin_ctzll(todo);         // lowest lane of the group
+      todo &= ~(((uint64_t(1) << G) - 1) << src);
+      const int64_t f = __shfl(first, src), ch = __shfl(chunk, src);
+      float part[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) part[i] = 0.f;
+      if (cols) {
+        constexpr int HU = FU / 2;
+        int64_t c = f + 1 + lane / G;
+        for (; c + static_cast<int64_t>(HU - 1) * GPW <= ch; c += static_cast<int64_t>(HU) * GPW) {
+          float t[HU][VEC];
+#pragma unroll
+          for (int u = 0; u < HU; ++u) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) t[u][i] = 0.f;
+            carry_add<VEC>(p + 2 * (c + static_cast<int64_t>(u) * GPW) * a.dpad, t[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < HU; ++u)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) part[i] += t[u][i];
+        }
+        for (; c <= ch; c += GPW) carry_add<VEC>(p + 2 * c * a.dpad, part);
+      }
+#pragma unroll
+      for (int off = G; off < kWave; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) part[i] += __shfl_xor(part[i], off);
+      if (lane / G == src / G)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += part[i];
+    }
+  }
+  if (active && cols) store_out<T, VEC>(a, r0, c0, acc);
 }
 
 // ---- rows without edges: act(bias) -------------------------------------------------------------
@@ -896,6 +951,23 @@ LPG_EXPORT int lpg_csr_spmm_phase_ms(float* out_ms) {
 }
 
 LPG_EXPORT int lpg_spmm_chunk_edges(int64_t e_cap) { return chunk_for(e_cap); }
+
+// the association order of the fix-up, for the same-order oracle (oracle/spmm_ref.c): a row whose pieces after the first
+// number more than lpg_spmm_fixup_long_row() is summed as `groups` interleaved left-to-right sub-sums (piece j goes to
+// sub-sum j % groups) folded by a balanced binary tree; shorter rows left to right.  `wide` = d, ldx, ldy multiples of
+// 16 bytes and x, y 16-byte aligned (what selects the 16-byte-per-lane kernels).
+LPG_EXPORT int lpg_spmm_fixup_groups(int64_t d, int elem_bytes, int wide) {
+  if (d < 1 || (elem_bytes != 2 && elem_bytes != 4)) return LPG_E_INVALID;
+  if (d == 1 || d == 2 || d == 4 || d == 8 || d == 16) {
+    if (!options().spmm_no_edge) return kWave / static_cast<int>(d);
+  }
+  const int vec = wide ? 16 / elem_bytes : 1;
+  const int64_t lanes = ceil_div(d, vec);
+  int g = 1;
+  while (g < lanes && g < kWave) g *= 2;
+  return kWave / g;
+}
+LPG_EXPORT int lpg_spmm_fixup_long_row(void) { return kFixupLongRow; }
 
 LPG_EXPORT int64_t lpg_csr_spmm_bytes(int64_t e_cap, int64_t d) {
   if (e_cap < 0 || d < 1) return LPG_E_INVALID;

@@ -23,16 +23,17 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
-def spmm_f32_chunked(rowptr, col, val, x, chunk):
-    """fp32 SpMM in the HIP kernel's association order (bit-exact comparison target)."""
+def spmm_f32_chunked(rowptr, col, val, x, chunk, groups=1, long_row=-1):
+    """fp32 SpMM in the HIP kernel's association order (bit-exact comparison target).  groups / long_row: the fix-up's
+    order for rows of more than long_row pieces after the first (lpg_spmm_fixup_groups / lpg_spmm_fixup_long_row)."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     col = np.ascontiguousarray(col, dtype=np.int32)
     val = None if val is None else np.ascontiguousarray(val, dtype=np.float32)
     x = np.ascontiguousarray(x, dtype=np.float32)
     n, d = len(rowptr) - 1, x.shape[1]
     y = np.empty((n, d), dtype=np.float32)
-    load().lpg_oracle_spmm_f32_chunked(_p(rowptr), _p(col), _p(val), _p(x), ctypes.c_int64(n), ctypes.c_int64(d),
-                                       ctypes.c_int64(chunk), _p(y))
+    load().lpg_oracle_spmm_f32_chunked2(_p(rowptr), _p(col), _p(val), _p(x), ctypes.c_int64(n), ctypes.c_int64(d),
+                                        ctypes.c_int64(chunk), ctypes.c_int64(groups), ctypes.c_int64(long_row), _p(y))
     return y
 
 

@@ -25,6 +25,8 @@ def test_workspace_queries_and_errors():
     lib = lpgnn_amd.load_library()
     assert lib.lpg_abi_version() == 1
     assert lib.lpg_spmm_chunk_edges(1000) == 16 and lib.lpg_spmm_chunk_edges(100_000_000) == 512
+    assert lib.lpg_spmm_fixup_groups(128, 4, 1) == 2 and lib.lpg_spmm_fixup_groups(32, 4, 1) == 8 and lib.lpg_spmm_fixup_groups(3, 4, 0) == 16
+    assert lib.lpg_spmm_fixup_groups(256, 4, 1) == 1 and lib.lpg_spmm_fixup_groups(128, 2, 1) == 4 and lib.lpg_spmm_fixup_long_row() == 64
     T = lib.lpg_spmm_chunk_edges(5_000_000)
     assert T % 16 == 0 and lib.lpg_csr_spmm_bytes(5_000_000, 128) == 2 * (-(-5_000_000 // T)) * 128 * 4 + 256
     assert lib.lpg_csr_spmm_bytes(-1, 128) < 0

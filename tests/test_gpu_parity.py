@@ -1984,10 +1984,43 @@ def test_spmm_bit_exact_vs_same_order_c_loop(dev, lpg_options, d, weighted, chun
     g = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n_rows, n_cols,
                                            None if w is None else torch.from_numpy(w).to(dev))
     y = _np(g.spmm(torch.from_numpy(x).to(dev)))
-    chunk = lpgnn_amd.load_library().lpg_spmm_chunk_edges(g.e_cap)
+    lib = lpgnn_amd.load_library()
+    chunk = lib.lpg_spmm_chunk_edges(g.e_cap)
     rowptr, col, val, _ = agg.coo_to_csr(ei[1], ei[0], n_rows, w)
-    want = spmm_c.spmm_f32_chunked(rowptr, col, val, x, chunk)
+    # hub rows of more than lpg_spmm_fixup_long_row() pieces are folded by the wave's lane groups (a fixed tree order)
+    groups, long_row = lib.lpg_spmm_fixup_groups(d, 4, int(d % 4 == 0)), lib.lpg_spmm_fixup_long_row()
+    want = spmm_c.spmm_f32_chunked(rowptr, col, val, x, chunk, groups, long_row)
     assert np.array_equal(y, want), float(np.abs(y - want).max())
+
+
+@pytest.mark.parametrize("d,weighted", [(32, True), (128, False), (3, True), (64, False), (256, True), (20, True)])
+def test_spmm_hub_rows_fixup_bit_exact(dev, d, weighted):
+    """rows of hundreds of chunks (hubs): their fix-up is shared by the lane groups of a wave -- sub-sums of every
+    groups-th piece folded by a balanced tree (lpg_spmm_fixup_groups / _long_row) -- and still equals the same-order C
+    loop bit for bit; the one-group order (groups = 1) must NOT match, or the test does not exercise the path.  (d = 1, 2,
+    4, 8, 16 take the edge-parallel kernel, whose in-chunk order is a lane tree: covered by the tolerance tests.)"""
+    import lpgnn_amd
+    from oracle import aggregation as agg, spmm_c
+    rng = np.random.default_rng(90 + d)
+    n_rows, n_cols = 400, 3000
+    lens = rng.integers(0, 12, n_rows)
+    lens[[7, 8, 311]] = (5000, 1100, 2077)                 # 312 / 68 / 129 pieces of 16 edges; two hubs are neighbours
+    dst = np.repeat(np.arange(n_rows), lens)
+    ei = np.stack([rng.integers(0, n_cols, dst.size), dst]).astype(np.int64)
+    w = rng.standard_normal(ei.shape[1]).astype(np.float32) if weighted else None
+    x = rng.standard_normal((n_cols, d)).astype(np.float32)
+    g = lpgnn_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n_rows, n_cols,
+                                           None if w is None else torch.from_numpy(w).to(dev))
+    y = _np(g.spmm(torch.from_numpy(x).to(dev)))
+    lib = lpgnn_amd.load_library()
+    chunk = lib.lpg_spmm_chunk_edges(g.e_cap)
+    groups, long_row = lib.lpg_spmm_fixup_groups(d, 4, int(d % 4 == 0)), lib.lpg_spmm_fixup_long_row()
+    rowptr, col, val, _ = agg.coo_to_csr(ei[1], ei[0], n_rows, w)
+    assert chunk == 16 and int(np.diff(rowptr).max()) // chunk > long_row
+    want = spmm_c.spmm_f32_chunked(rowptr, col, val, x, chunk, groups, long_row)
+    assert np.array_equal(y, want), float(np.abs(y - want).max())
+    if groups > 1:
+        assert not np.array_equal(y, spmm_c.spmm_f32_chunked(rowptr, col, val, x, chunk))
 
 
 @pytest.mark.parametrize("d,weighted", [(32, True), (128, False), (8, True), (256, True)])
