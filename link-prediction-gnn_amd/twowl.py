@@ -117,6 +117,7 @@ def tuple_graph(n_node: int, pos_edge, pred_edge):
 
 
 _TABLE_CONV1 = True            # kernel-per-op path: GraphNorm + conv1's linear on the embedding TABLE rows (see _one_wl_stage)
+_TABLE_COMPACT_MIN = 4096      # embedding tables longer than this are compacted to the rows in use (_index_classes)
 _IMPLICIT_MODE = "node"        # "node": per-node sums all the way (csrc/tuple_wl.hip); "operator": GCNConv per orientation
 _side_streams = {}
 _PARALLEL_BRANCHES = os.environ.get("LPG_TWOWL_PARALLEL", "1") != "0"
@@ -351,13 +352,25 @@ class LocalWLNet(nn.Module):
         the degree histogram) and conv1's linear run on the TABLE rows and the node rows are gathered from the product
         -- [V, C1] instead of [N, C1] through three memory-bound passes (_TABLE_CONV1 = False keeps those)."""
         convs = list(self.conv1s)
+        table_rows = 0
         if (_TABLE_CONV1 and not self.use_node_feat and convs and _is_relu_conv(convs[0]) and x.is_cuda
-                and not isinstance(edge1, _ops.CSRGraph) and x.numel() >= 4 * self.emb[0].weight.shape[0]):
+                and not isinstance(edge1, _ops.CSRGraph)):
+            table_rows = V = self.emb[0].weight.shape[0]
+            if V > _TABLE_COMPACT_MIN:
+                # only the degrees that occur: [D, C1] rows instead of [V, C1] (rows nobody indexes have weight 0 in the
+                # statistics and are never gathered).  A skewed graph's largest degree is of the order of its node count
+                # (ppa-shaped: 3 * 10^5 for 5.8 * 10^5 nodes) while a few thousand distinct degrees occur.
+                rows, hist_c, xr = _index_classes(x, V)
+                table_rows = rows.numel()
+        if table_rows and x.numel() >= 4 * table_rows:
             table, nm, seq = self.emb[0].weight, self.emb[1], convs.pop(0)
             n = x.numel()
-            hist = _index_histogram(x, table.shape[0])                                 # index range checked here; memoised
+            if table_rows < table.shape[0]:
+                table, hist, x = _ops.embedding(table, rows), hist_c, xr
+            else:
+                hist = _index_histogram(x, table.shape[0])                             # index range checked here; memoised
             tn = _ops.graph_norm_weighted(table, hist, n, nm.weight, nm.bias, nm.mean_scale, nm.eps)
-            hv = _ops.linear(tn, seq.modlist[0].lin.weight)                            # [V, C_out]
+            hv = _ops.linear(tn, seq.modlist[0].lin.weight)                            # [V or D, C_out]
             h = _ops.embedding(hv, x)
             g1 = graph_cache.get(edge1, None, n, True)
             y = g1.spmm(h, bias=seq.modlist[0].bias)
@@ -493,6 +506,22 @@ def _index_histogram(x, n_bins):
             _hist_cache.clear()
         hit = _hist_cache[key] = (_ops.degree(x.reshape(-1), n_bins), x)        # holds x: its storage cannot be recycled
     return hit[0]
+
+
+def _index_classes(x, n_bins):
+    """(rows, counts, xr) for an index vector: rows = the DISTINCT values present, ascending (int64 [D]), counts = how
+    often each occurs (int64 [D]), xr = x renamed to 0..D-1 (same shape as x) -- memoised with the histogram.  The 1-WL
+    table stage works on D rows instead of n_bins: on a ppa-shaped graph the largest degree is 3 * 10^5 (n_bins rows of
+    256 floats = 334 MB through three passes) while only a few thousand distinct degrees occur."""
+    key = (x.data_ptr(), x._version, x.numel(), x.device, n_bins)
+    hist = _index_histogram(x, n_bins)
+    hit = _hist_cache[key]
+    if len(hit) < 3:
+        present = hist > 0
+        rows = torch.nonzero(present).reshape(-1)                          # one host sync per index vector
+        rank = torch.cumsum(present, 0) - 1
+        hit = _hist_cache[key] = hit + ((rows, hist[rows].contiguous(), rank[x.reshape(-1).clamp(0, n_bins - 1)].reshape(x.shape)),)
+    return hit[2]
 
 
 class CapturedForward:

@@ -2606,8 +2606,11 @@ def test_graph_norm_weighted_table_and_conv1_on_table_rows(dev, tw, monkeypatch)
     mod, x_deg, ei, pred, ei2, pos1 = _localwl_case(tw, 64, 24, 2, 1, dev)
     cases.append((mod, x_deg, ei))
     N, E = 20_000, 120_000
-    pe = twowl_int.double(rng.integers(0, N, size=(2, E)))
+    und = rng.integers(0, N, size=(2, E))
+    und[0, :6000] = 7                                       # a hub: max degree ~6000, a few dozen distinct degrees in use
+    pe = twowl_int.double(und)
     deg = np.bincount(pe[0], minlength=N).astype(np.int64)
+    assert deg.max() > twowl._TABLE_COMPACT_MIN             # the default takes the compacted table here
     torch.manual_seed(2)
     cases.append((twowl.LocalWLNet(int(deg.max()), channels_1wl=32, channels_2wl=16).to(dev).eval(), deg, pe))
     for mod, x_deg, ei in cases:
@@ -2619,8 +2622,9 @@ def test_graph_norm_weighted_table_and_conv1_on_table_rows(dev, tw, monkeypatch)
             if p[f"conv1s.{l}.act"]:
                 x = np.maximum(x, 0.0)
         outs = []
-        for flag in (True, False):
+        for flag, compact_min in ((True, 4096), (True, 0), (True, 1 << 60), (False, 4096)):   # default / always / never compacted / row by row
             monkeypatch.setattr(twowl, "_TABLE_CONV1", flag)
+            monkeypatch.setattr(twowl, "_TABLE_COMPACT_MIN", compact_min)
             with torch.no_grad():
                 outs.append(_np(mod._one_wl_stage(t(x_deg), t(ei))).astype(np.float64))
         scale = np.abs(x).max()
