@@ -225,6 +225,12 @@ int lpg_graphnorm_weighted_f32(const float* x, int64_t n, int64_t d, const int64
  * flip_index: edge = (flip(e0), e1), edge_r = (e0, flip(e1)), flip(k) = k^1 [TwoWL/utils.py:71-78] */
 int lpg_embedding_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* idx,
                       int64_t n, float* out, int32_t* err_flag, void* stream);
+/* the same with every gathered row multiplied by row_scale[i] (out[i] = row_scale[i] * table[idx[i]]): the D^-1/2 of a
+ * unit-weight GCN normalisation folded into the gather, so that the SpMM after it runs unweighted with row_scale =
+ * D^-1/2 (twowl._one_wl_stage).  Needs 16-byte aligned rows, d % 4 == 0, d / 4 a divisor of 256. */
+int lpg_embedding_scaled_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* idx,
+                             int64_t n, const float* row_scale, float* out, int32_t* err_flag,
+                             void* stream);
 int lpg_pair_gather_mul_f32(const float* x, int64_t n, int64_t d, const int64_t* pos, int64_t P,
                             float* h, int32_t* err_flag, void* stream);
 int lpg_pair_readout_f32(const float* h, int64_t P, int64_t d, const int64_t* idx, int64_t B,

@@ -55,16 +55,19 @@ __global__ __launch_bounds__(kBlock) void pair_mul_kernel(const float* __restric
 constexpr int kRowsU = 8;
 __global__ __launch_bounds__(kBlock) void embedding_rows4_kernel(const float* __restrict__ table, int64_t n_rows,
                                                                  int64_t d, int dv, const int64_t* __restrict__ idx,
-                                                                 int64_t n, float* __restrict__ out, int32_t* err_flag) {
+                                                                 int64_t n, const float* __restrict__ scale,
+                                                                 float* __restrict__ out, int32_t* err_flag) {
   const int cv = threadIdx.x % dv, rin = threadIdx.x / dv, rpb = kBlock / dv;
   const int64_t step = static_cast<int64_t>(gridDim.x) * rpb * kRowsU;
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * rpb * kRowsU; base < n; base += step) {
     int64_t r[kRowsU];
+    float sc[kRowsU];
     bool ok[kRowsU];
 #pragma unroll
     for (int u = 0; u < kRowsU; ++u) {
       const int64_t i = base + u * rpb + rin;
       r[u] = idx[i < n ? i : n - 1];
+      sc[u] = scale ? scale[i < n ? i : n - 1] : 1.0f;     // scale is wave-uniformly given or not
     }
     float4 v[kRowsU];
 #pragma unroll
@@ -77,7 +80,9 @@ __global__ __launch_bounds__(kBlock) void embedding_rows4_kernel(const float* __
     }
 #pragma unroll
     for (int u = 0; u < kRowsU; ++u)
-      if (ok[u]) store_stream(out + (base + u * rpb + rin) * d + 4 * cv, v[u]);
+      if (ok[u])
+        store_stream(out + (base + u * rpb + rin) * d + 4 * cv,
+                     scale ? make_float4(v[u].x * sc[u], v[u].y * sc[u], v[u].z * sc[u], v[u].w * sc[u]) : v[u]);
   }
 }
 
@@ -154,6 +159,17 @@ __global__ __launch_bounds__(kBlock) void flip_kernel(const int64_t* __restrict_
 inline bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 }  // namespace
 
+LPG_EXPORT int lpg_embedding_scaled_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* idx, int64_t n,
+                                        const float* row_scale, float* out, int32_t* err_flag, void* stream) {
+  LPG_REQUIRE(n >= 0 && d >= 1 && n_rows >= 1, "embedding_scaled: bad sizes");
+  if (n == 0) return LPG_OK;
+  LPG_REQUIRE(table && idx && out && row_scale, "embedding_scaled: null pointer");
+  LPG_REQUIRE(rows4_ok(d) && al16(table) && al16(out), "embedding_scaled: needs 16-byte aligned rows of d %% 4 == 0, d / 4 a divisor of 256");
+  hipLaunchKernelGGL(embedding_rows4_kernel, dim3(grid_for(ceil_div(n * (d / 4), kRowsU))), dim3(kBlock), 0, as_stream(stream),
+                     table, n_rows, d, static_cast<int>(d / 4), idx, n, row_scale, out, err_flag);
+  return check_launch("embedding_scaled");
+}
+
 LPG_EXPORT int lpg_embedding_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* idx, int64_t n,
                                  float* out, int32_t* err_flag, void* stream) {
   LPG_REQUIRE(n >= 0 && d >= 1 && n_rows >= 0, "embedding: bad sizes");
@@ -161,7 +177,8 @@ LPG_EXPORT int lpg_embedding_f32(const float* table, int64_t n_rows, int64_t d, 
   LPG_REQUIRE(table && idx && out, "embedding: null pointer");
   if (rows4_ok(d) && al16(table) && al16(out) && n_rows > 0)
     hipLaunchKernelGGL(embedding_rows4_kernel, dim3(grid_for(ceil_div(n * (d / 4), kRowsU))), dim3(kBlock), 0,
-                       as_stream(stream), table, n_rows, d, static_cast<int>(d / 4), idx, n, out, err_flag);
+                       as_stream(stream), table, n_rows, d, static_cast<int>(d / 4), idx, n, static_cast<const float*>(nullptr), out,
+                       err_flag);
   else if (d % 4 == 0 && al16(table) && al16(out))
     hipLaunchKernelGGL(embedding_kernel<4>, dim3(grid_for(n * d / 4)), dim3(kBlock), 0, as_stream(stream), table,
                        n_rows, d, idx, n, out, err_flag);

@@ -461,12 +461,21 @@ def graph_norm_weighted(x, row_weight, n_total, weight, bias, mean_scale, eps=1e
 
 
 # ------------------------------------------------------------------------------ pair ops
-def embedding(table, idx):
+def embedding(table, idx, row_scale=None):
+    """table[idx] (row_scale: every gathered row i times row_scale[i], fp32 [n])"""
     lib = _lib.load()
-    _need_gpu(table, idx)
+    _need_gpu(table, idx, row_scale)
     table = _c(table, torch.float32)
     idx = _c(idx.reshape(-1), torch.int64)
     out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    if row_scale is not None:
+        row_scale = _c(row_scale.reshape(-1), torch.float32)
+        if row_scale.numel() != idx.numel():
+            raise ValueError("embedding: row_scale needs one value per index")
+        _lib.check(lib.lpg_embedding_scaled_f32(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(),
+                                                _ptr(row_scale), _ptr(out), _ptr(err_flag(table.device)), _stream()),
+                   "embedding_scaled")
+        return out
     _lib.check(lib.lpg_embedding_f32(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(), _ptr(out),
                                      _ptr(err_flag(table.device)), _stream()), "embedding")
     return out

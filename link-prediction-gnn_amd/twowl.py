@@ -371,9 +371,15 @@ class LocalWLNet(nn.Module):
                 hist = _index_histogram(x, table.shape[0])                             # index range checked here; memoised
             tn = _ops.graph_norm_weighted(table, hist, n, nm.weight, nm.bias, nm.mean_scale, nm.eps)
             hv = _ops.linear(tn, seq.modlist[0].lin.weight)                            # [V or D, C_out]
-            h = _ops.embedding(hv, x)
             g1 = graph_cache.get(edge1, None, n, True)
-            y = g1.spmm(h, bias=seq.modlist[0].bias)
+            co = hv.shape[1]
+            if g1.unit_gcn and g1.dinv is not None and co % 4 == 0 and 256 % (co // 4) == 0:
+                # unit edge weights: D^-1/2 (A + I) D^-1/2 h = D^-1/2 ((A + I) (D^-1/2 h)) -- the column factor rides on the
+                # gather, the row factor on the SpMM's epilogue, and the SpMM reads no edge values (ppa-shaped graph, 61 M
+                # entries at d = 32: 1.04 -> 0.86 ms)
+                y = g1.spmm(_ops.embedding(hv, x, row_scale=g1.dinv), row_scale=g1.dinv, bias=seq.modlist[0].bias, use_val=False)
+            else:
+                y = g1.spmm(_ops.embedding(hv, x), bias=seq.modlist[0].bias)
             x = seq.modlist[1](y, relu=isinstance(seq.modlist[3], nn.ReLU))
         else:
             x = self._input_features(x)
