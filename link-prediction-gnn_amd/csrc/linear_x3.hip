@@ -521,7 +521,10 @@ int linear_x3_f32(const float* x, int64_t ldx, const float* w, int w_is_km, cons
   const int cus = cus_of[dev];
   // the tiled form: k % 32 == 0, m % 128 == 0, W [m][k] 16-byte aligned, bias (if any) 16-byte aligned
   const bool tiled_ok = !w_is_km && k % 32 == 0 && m % kTileC == 0 && al16(w) && (!bias || al16(bias)) && k >= 32;
-  if (tiled_ok && (mode == 2 || (mode < 0 && options().linear_wres <= 0 && n >= 16384))) {
+  // automatic: from 16 K rows; at k m <= 128 x 128 only up to 512 K rows (beyond, the strip form with all of W resident
+  // is 3-5 % ahead: 5 M x 128 -> 128 1.24 against 1.30 ms, profiles/r03/linear_x3_tiled.log)
+  const bool tiled_auto = mode < 0 && options().linear_wres <= 0 && n >= 16384 && (k * m > 128 * 128 || n <= (int64_t(1) << 19));
+  if (tiled_ok && (mode == 2 || tiled_auto)) {
     const int rc = launch_x3t(x, ldx, w, bias, act, y, ldy, n, static_cast<int>(k), static_cast<int>(m), cus, st);
     if (rc == 1) ++options_mut().stat_linear_x3;
     if (rc != 0) return rc;
