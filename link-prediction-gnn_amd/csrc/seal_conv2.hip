@@ -131,6 +131,23 @@ struct RowCtxT {
 // fp32 variant without the head (what a caller who wants concat(Z1, Z2, Z3) as SEAL/model/gnn.py:63 produces it gets)
 // needs its 9 KB transposition slice but not the 9.8 KB of k1 fragments -- with both it was 89 KB, ONE workgroup per CU
 // instead of two ("desired occupancy was 2, final occupancy is 1"; 1.13 ms per 100 K candidates against 0.58 fused).
+// -DLPG_TUNING builds only (profiles/seal_conv_phases.py): where a workgroup's time per 128-row window goes, in ticks of
+// the 100 MHz wall clock summed over the launch -- [0] prologue (window bounds, per-row tables, gathers, planes),
+// [1] the layers, [2] SortPooling epilogue, [3] windows.  Stamps sit right behind barriers the kernel has anyway.
+#ifdef LPG_TUNING
+__device__ unsigned long long g_conv_phase[4];
+#define CONV_PHASE(k)                                                \
+  do {                                                               \
+    if (threadIdx.x == 0) {                                          \
+      const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+      cph_acc[k] += now_ - cph_t0;                                   \
+      cph_t0 = now_;                                                 \
+    }                                                                \
+  } while (0)
+#else
+#define CONV_PHASE(k) do { } while (0)
+#endif
+
 template <int NP, typename TIN, bool CAT, bool K1>
 __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_conv_t2_kernel(
     const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
@@ -204,8 +221,14 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
   }
   }
   const int64_t nwin = total_ptr ? (total_ptr[0] + WIN - 1) / WIN : n_windows;
+#ifdef LPG_TUNING
+  unsigned long long cph_acc[4] = {0, 0, 0, 0}, cph_t0 = 0;
+#endif
   for (int64_t win_id = blockIdx.x; win_id < nwin; win_id += gridDim.x) {
   __syncthreads();                                  // the previous window's last readers of the planes / tables are done
+#ifdef LPG_TUNING
+  if (threadIdx.x == 0) cph_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // the thread's coordinates are re-derived per window behind an opaque zero: with loop-invariant lane arithmetic the
   // compiler hoisted every LDS / global address of the body out of the window loop and kept ~70 more VGPRs live
   // (186 -> 250, the bf16 kernel lost its third wave per SIMD)
@@ -292,6 +315,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
     });
     __syncthreads();
   }
+  CONV_PHASE(0);
 
   auto row_ctx = [&](int I) {
     RowCtxT c{-100000, 0, 0.f, 0x3F80u, 0u, 0u, 0u, 0u, 0, -1};
@@ -505,6 +529,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
     }
     __syncthreads();
   }
+  CONV_PHASE(1);
   if (fx.pooled && k1) {
     // ---- SortPooling in the epilogue (SEAL/model/gnn.py:82-91): per subgraph the pool_k rows with the largest keys,
     // key descending, ties by vertex index, NaN last (the total order of seal_sortpool_kernel); missing rows are zero.
@@ -562,7 +587,15 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
         reinterpret_cast<float4*>(fx.pooled + (static_cast<int64_t>(bf + q) * pk + rr) * 16)[rem & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+#ifdef LPG_TUNING
+  CONV_PHASE(2);
+  if (threadIdx.x == 0) cph_acc[3] += 1ull;
+#endif
   }   // windows
+#ifdef LPG_TUNING
+  if (threadIdx.x == 0 && cph_acc[3])
+    for (int k = 0; k < 4; ++k) atomicAdd(&g_conv_phase[k], cph_acc[k]);
+#endif
 }
 
 // workgroups of `kernel` the chip holds at once (occupancy x CUs); 512 if the runtime cannot say
@@ -694,4 +727,21 @@ LPG_EXPORT int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* 
               "seal_conv_stack_bf16: h1 / cat must be 8-byte aligned, head_a16 16-byte aligned");
   return launch_conv2<1, uint16_t>(node_off, first, n_windows, adj_bits, h1, ldh, w2, w3, w4, cat, ldc, key, head_k1, head_a16,
                                    ConvFuse{}, as_stream(stream));
+}
+
+LPG_EXPORT int lpg_seal_conv_phase_ticks(uint64_t* out4_host, int reset) {
+#ifdef LPG_TUNING
+  LPG_REQUIRE(out4_host, "seal_conv_phase_ticks: null pointer");
+  LPG_HIP(hipDeviceSynchronize());
+  LPG_HIP(hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_conv_phase), 4 * sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    LPG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase), zero, sizeof(zero)));
+  }
+  return LPG_OK;
+#else
+  (void)out4_host; (void)reset;
+  set_error("seal_conv_phase_ticks: only in a -DLPG_TUNING build of the library");
+  return LPG_E_INVALID;
+#endif
 }
