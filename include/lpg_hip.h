@@ -473,9 +473,10 @@ int lpg_seal_subgraphs(const int64_t* adj_rowptr, const int32_t* adj_col, int64_
  * teams -- out8[0..6] = node set, row descriptors + filter, streamed lists, hub bit matrix, searches, DRNL, outputs;
  * out8[7] = pairs handled by teams.  out8_host is HOST memory; synchronises the device. */
 int lpg_seal_phase_ticks(uint64_t* out8_host, int reset);
-/* the same for the SEAL conv stack's 128-row windows: [0] prologue, [1] layers, [2] SortPooling epilogue, [3] windows
+/* the same for the SEAL conv stack's 128-row windows, EIGHT values: [1] layers, [2] SortPooling epilogue, [3] windows,
+ * prologue steps [4] bounds + offsets, [5] row table + tags / nodes, [7] table gathers + planes ([0], [6] unused)
  * (-DLPG_TUNING builds only; profiles/seal_conv_phases.py) */
-int lpg_seal_conv_phase_ticks(uint64_t* out4_host, int reset);
+int lpg_seal_conv_phase_ticks(uint64_t* out8_host, int reset);
 
 /* Block-diagonal CSR of A~ = A + I over a batch, D^-1 = 1/rowsum(A~), and
  * X = [onehot(tag_map[tag], T) || emb[node]]  [SEAL/config/data.py:94-140].

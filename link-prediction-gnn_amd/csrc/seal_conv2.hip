@@ -132,10 +132,11 @@ struct RowCtxT {
 // needs its 9 KB transposition slice but not the 9.8 KB of k1 fragments -- with both it was 89 KB, ONE workgroup per CU
 // instead of two ("desired occupancy was 2, final occupancy is 1"; 1.13 ms per 100 K candidates against 0.58 fused).
 // -DLPG_TUNING builds only (profiles/seal_conv_phases.py): where a workgroup's time per 128-row window goes, in ticks of
-// the 100 MHz wall clock summed over the launch -- [0] prologue (window bounds, per-row tables, gathers, planes),
-// [1] the layers, [2] SortPooling epilogue, [3] windows.  Stamps sit right behind barriers the kernel has anyway.
+// the 100 MHz wall clock summed over the launch -- [1] the layers, [2] SortPooling epilogue, [3] windows, and the prologue
+// in steps: [4] window bounds + subgraph offsets, [5] row table + tags / nodes, [7] table gathers + plane split.  Stamps sit
+// right behind barriers the kernel has anyway.
 #ifdef LPG_TUNING
-__device__ unsigned long long g_conv_phase[4];
+__device__ unsigned long long g_conv_phase[8];
 #define CONV_PHASE(k)                                                \
   do {                                                               \
     if (threadIdx.x == 0) {                                          \
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
   }
   const int64_t nwin = total_ptr ? (total_ptr[0] + WIN - 1) / WIN : n_windows;
 #ifdef LPG_TUNING
-  unsigned long long cph_acc[4] = {0, 0, 0, 0}, cph_t0 = 0;
+  unsigned long long cph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cph_t0 = 0;
 #endif
   for (int64_t win_id = blockIdx.x; win_id < nwin; win_id += gridDim.x) {
   __syncthreads();                                  // the previous window's last readers of the planes / tables are done
@@ -249,18 +250,34 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
   // `piece(row, kq, v)` yields the four values: a 16-byte read of h1, or (tables mode, after the row table below) the
   // sum of two 16-byte gathers.
   auto fill_planes = [&](auto piece) {
-    for (int idx = tid; idx < ntiles * 128; idx += kConvBlock) {
-      const int g = idx >> 6, l = idx & 63;
-      const int rp = (g >> 1) * 16 + (l & 15), kq = (g & 1) * 4 + (l >> 4), row = 2 * rp;
-      float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};   // rows past the end are zero (0 x NaN is not)
-      if (row < nrows) piece(row, kq, v0);
-      if (row + 1 < nrows) piece(row + 1, kq, v1);
+    // U items per thread and step: every gather of the step is issued before the first plane is split (the fp32 kernel
+    // has the registers for two: a 128-row window is then ONE round trip to the tables instead of two)
+    constexpr int U = NP == 3 ? 2 : 1;
+    for (int idx0 = tid; idx0 < ntiles * 128; idx0 += U * kConvBlock) {
+      float v0[U][4], v1[U][4];
+      int rows[U], kqs[U];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint32_t pr[NP];
-        planes_pair<NP>(v0[j], v1[j], pr);
+      for (int u = 0; u < U; ++u) {
+        const int idx = idx0 + u * kConvBlock;
+        const int g = idx >> 6, l = idx & 63;
+        const int rp = (g >> 1) * 16 + (l & 15);
+        kqs[u] = (g & 1) * 4 + (l >> 4);
+        rows[u] = idx < ntiles * 128 ? 2 * rp : nrows;                    // beyond the window: nothing to read or write
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kq + j][row]) = pr[p];
+        for (int j = 0; j < 4; ++j) v0[u][j] = v1[u][j] = 0.f;             // rows past the end are zero (0 x NaN is not)
+        if (rows[u] < nrows) piece(rows[u], kqs[u], v0[u]);
+        if (rows[u] + 1 < nrows) piece(rows[u] + 1, kqs[u], v1[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (idx0 + u * kConvBlock >= ntiles * 128) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint32_t pr[NP];
+          planes_pair<NP>(v0[u][j], v1[u][j], pr);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) *reinterpret_cast<uint32_t*>(&Hp[p][4 * kqs[u] + j][rows[u]]) = pr[p];
+        }
       }
     }
   };
@@ -284,14 +301,19 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
   // ---- per-subgraph offsets, per-row (subgraph, vertex)
   for (int q = tid; q <= nsub; q += kConvBlock) soff[q] = static_cast<int>(node_off[bf + q] - r_lo);
   __syncthreads();
-  for (int q = tid; q < nsub; q += kConvBlock)
-    for (int lr = soff[q]; lr < soff[q + 1]; ++lr) rinfo[lr] = (static_cast<uint32_t>(q) << 8) | static_cast<uint32_t>(lr - soff[q]);
-  __syncthreads();
-  if (!h1) {
-    // tables mode: per row its (node, tag column), then the planes from W_1[tag] + P[node] (fp32 sum; NP = 1 rounds it
-    // once to bf16 -- bit for bit what lpg_seal_h1_tables_f32 / _bf16 followed by the h1 read above gives)
-    for (int lr = tid; lr < nrows; lr += kConvBlock) {
-      const uint32_t ri = rinfo[lr];
+  CONV_PHASE(4);
+  // a thread per ROW finds its subgraph by bisection over the <= 129 offsets (a thread per SUBGRAPH writing its rows one
+  // after the other was 2.1 of the prologue's 6.3 us on the reference's candidate mix: 54 dependent LDS writes)
+  for (int lr = tid; lr < nrows; lr += kConvBlock) {
+    int lo = 0, hi = nsub;                           // the last q with soff[q] <= lr (an empty subgraph shares its offset
+    while (hi - lo > 1) {                            // with its successor and is skipped: the successor is the last)
+      const int mid = (lo + hi) >> 1;
+      if (soff[mid] <= lr) lo = mid; else hi = mid;
+    }
+    const uint32_t ri = (static_cast<uint32_t>(lo) << 8) | static_cast<uint32_t>(lr - soff[lo]);
+    rinfo[lr] = ri;
+    if (!h1) {
+      // tables mode: the row's (node, tag column) in the same pass -- no barrier between the row table and its first use
       const int64_t slot = static_cast<int64_t>(bf + (ri >> 8)) * MAXN + (ri & 255u);
       int32_t tg = fx.tags[slot];
       const int32_t nd = fx.nodes[slot];
@@ -305,7 +327,12 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
       rnode[lr] = ok ? nd : -1;
       rtag[lr] = static_cast<uint16_t>(ok ? tg : 0);
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  CONV_PHASE(5);
+  if (!h1) {
+    // tables mode: per row its (node, tag column), then the planes from W_1[tag] + P[node] (fp32 sum; NP = 1 rounds it
+    // once to bf16 -- bit for bit what lpg_seal_h1_tables_f32 / _bf16 followed by the h1 read above gives)
     fill_planes([&](int row, int kq, float (&v)[4]) {
       const int32_t nd = rnode[row];
       if (nd < 0) return;                              // an invalid row stays zero, as the tables kernel leaves it
@@ -315,7 +342,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
     });
     __syncthreads();
   }
-  CONV_PHASE(0);
+  CONV_PHASE(7);
 
   auto row_ctx = [&](int I) {
     RowCtxT c{-100000, 0, 0.f, 0x3F80u, 0u, 0u, 0u, 0u, 0, -1};
@@ -594,7 +621,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
   }   // windows
 #ifdef LPG_TUNING
   if (threadIdx.x == 0 && cph_acc[3])
-    for (int k = 0; k < 4; ++k) atomicAdd(&g_conv_phase[k], cph_acc[k]);
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_conv_phase[k], cph_acc[k]);
 #endif
 }
 
@@ -729,18 +756,18 @@ LPG_EXPORT int lpg_seal_conv_stack_bf16(const int64_t* node_off, const int32_t* 
                                    ConvFuse{}, as_stream(stream));
 }
 
-LPG_EXPORT int lpg_seal_conv_phase_ticks(uint64_t* out4_host, int reset) {
+LPG_EXPORT int lpg_seal_conv_phase_ticks(uint64_t* out8_host, int reset) {
 #ifdef LPG_TUNING
-  LPG_REQUIRE(out4_host, "seal_conv_phase_ticks: null pointer");
+  LPG_REQUIRE(out8_host, "seal_conv_phase_ticks: null pointer");
   LPG_HIP(hipDeviceSynchronize());
-  LPG_HIP(hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_conv_phase), 4 * sizeof(unsigned long long)));
+  LPG_HIP(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_conv_phase), 8 * sizeof(unsigned long long)));
   if (reset) {
-    const unsigned long long zero[4] = {0, 0, 0, 0};
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     LPG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase), zero, sizeof(zero)));
   }
   return LPG_OK;
 #else
-  (void)out4_host; (void)reset;
+  (void)out8_host; (void)reset;
   set_error("seal_conv_phase_ticks: only in a -DLPG_TUNING build of the library");
   return LPG_E_INVALID;
 #endif
