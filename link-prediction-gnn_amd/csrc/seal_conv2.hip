@@ -136,7 +136,7 @@ struct RowCtxT {
 // in steps: [4] window bounds + subgraph offsets, [5] row table + tags / nodes, [7] table gathers + plane split.  Stamps sit
 // right behind barriers the kernel has anyway.
 #ifdef LPG_TUNING
-__device__ unsigned long long g_conv_phase[8];
+__device__ unsigned long long g_conv_phase[12];
 #define CONV_PHASE(k)                                                \
   do {                                                               \
     if (threadIdx.x == 0) {                                          \
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
   }
   const int64_t nwin = total_ptr ? (total_ptr[0] + WIN - 1) / WIN : n_windows;
 #ifdef LPG_TUNING
-  unsigned long long cph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cph_t0 = 0;
+  unsigned long long cph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cph_t0 = 0;
 #endif
   for (int64_t win_id = blockIdx.x; win_id < nwin; win_id += gridDim.x) {
   __syncthreads();                                  // the previous window's last readers of the planes / tables are done
@@ -528,6 +528,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
     }
     if (layer == 4) break;
     __syncthreads();                                 // every aggregation of this layer has read H
+    CONV_PHASE(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int I = wave + t * (kConvBlock / 64);
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
       }
     }
     __syncthreads();
+    CONV_PHASE(6);
   }
   CONV_PHASE(1);
   if (fx.pooled && k1) {
@@ -585,17 +587,24 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
       }
     }
     __syncthreads();
+    CONV_PHASE(8);
     const int pk = fx.pool_k;
-    for (int lr = tid; lr < nrows; lr += kConvBlock) {                // one thread per vertex: its rank inside its subgraph
+    // a PAIR of neighbouring lanes per vertex, each counting over half of the subgraph (a window has 128 rows on average:
+    // with a thread per vertex half of the workgroup idled through the kernel's one O(n^2) loop, 2.3 of 25 us per window)
+    for (int it = tid; it < 2 * ((nrows + 31) & ~31); it += kConvBlock) {   // whole waves: the shuffle below needs both lanes
+      const int lr = min(it >> 1, nrows - 1), half = it & 1;
       const uint32_t ri = rinfo[lr];
       const int q = static_cast<int>(ri >> 8), s0 = soff[q], n = soff[q + 1] - s0;
       const unsigned long long mine = comp[lr];
+      const int j0 = half ? (n >> 1) : 0, j1 = half ? n : (n >> 1);
       int rank = 0;
 #pragma unroll 4
-      for (int j = 0; j < n; ++j) rank += comp[s0 + j] > mine ? 1 : 0;
-      rtag[lr] = static_cast<uint16_t>(rank);         // (the tag columns are not needed any more)
+      for (int j = j0; j < j1; ++j) rank += comp[s0 + j] > mine ? 1 : 0;
+      rank += __shfl_xor(rank, 1);
+      if (half == 0 && (it >> 1) < nrows) rtag[lr] = static_cast<uint16_t>(rank);   // (the tag columns are not needed any more)
     }
     __syncthreads();
+    CONV_PHASE(9);
     // the kept rows leave as whole 64-byte pieces: four lanes per row, 16 rows per wave instruction (a thread per row
     // writing its four 16-byte pieces one after the other touched 64 different lines per instruction)
     for (int idx = tid; idx < nrows * 4; idx += kConvBlock) {
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_co
   }   // windows
 #ifdef LPG_TUNING
   if (threadIdx.x == 0 && cph_acc[3])
-    for (int k = 0; k < 8; ++k) atomicAdd(&g_conv_phase[k], cph_acc[k]);
+    for (int k = 0; k < 12; ++k) atomicAdd(&g_conv_phase[k], cph_acc[k]);
 #endif
 }
 
@@ -760,9 +769,9 @@ LPG_EXPORT int lpg_seal_conv_phase_ticks(uint64_t* out8_host, int reset) {
 #ifdef LPG_TUNING
   LPG_REQUIRE(out8_host, "seal_conv_phase_ticks: null pointer");
   LPG_HIP(hipDeviceSynchronize());
-  LPG_HIP(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_conv_phase), 8 * sizeof(unsigned long long)));
+  LPG_HIP(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_conv_phase), 12 * sizeof(unsigned long long)));
   if (reset) {
-    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     LPG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase), zero, sizeof(zero)));
   }
   return LPG_OK;

@@ -34,7 +34,7 @@ for label, pairs in (("uniform", uniform), ("refmix", refmix)):
     gw32 = [torch.randn(T + D, 32, device=dev) * 0.1] + w_rest
     for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
         gw, e = [w.to(dt) for w in gw32], emb.to(dt)
-        out = (ctypes.c_uint64 * 8)()
+        out = (ctypes.c_uint64 * 12)()
         seal.score_stack(batch, tag_map, T, e, gw, k1, pool_k=k)
         _lib.check(lib.lpg_seal_conv_phase_ticks(out, 1), "conv_phase_ticks")
         torch.cuda.synchronize()
@@ -45,10 +45,16 @@ for label, pairs in (("uniform", uniform), ("refmix", refmix)):
         ms = (time.perf_counter() - t0) / 5 * 1e3
         _lib.check(lib.lpg_seal_conv_phase_ticks(out, 1), "conv_phase_ticks")
         wins = max(out[3], 1)
-        out[0] = out[4] + out[5] + out[7]
-        tot = sum(out[:3])
+        pro = out[4] + out[5] + out[7]
+        lay = out[0] + out[6] + out[1]
+        epi = out[8] + out[9] + out[2]
+        sub = list(out)
+        out[0], out[1], out[2] = pro, lay, epi
+        tot = pro + lay + epi
         print(f"{label} {name}: {ms:.3f} ms per launch, {out[3] / 5:.0f} windows per launch, {tot / wins / 100:.2f} us per window "
               f"in its workgroup")
         for j in range(3):
             print(f"    {names[j]:18s} {out[j] / wins / 100:7.2f} us per window  {100.0 * out[j] / max(tot, 1):5.1f} %")
-        print("    prologue steps: " + ", ".join(f"{n} {out[j] / wins / 100:.2f}" for n, j in (("bounds + offsets", 4), ("row table + tags / nodes", 5), ("table gathers + planes", 7))))
+        print("    layer steps: " + ", ".join(f"{n} {sub[j] / wins / 100:.2f}" for n, j in (("aggregate + dense (to the barrier)", 0), ("plane writes", 6), ("layer 4", 1))))
+        print("    epilogue steps: " + ", ".join(f"{n} {sub[j] / wins / 100:.2f}" for n, j in (("rows + keys to LDS", 8), ("ranks", 9), ("stores", 2))))
+        print("    prologue steps: " + ", ".join(f"{n} {sub[j] / wins / 100:.2f}" for n, j in (("bounds + offsets", 4), ("row table + tags / nodes", 5), ("table gathers + planes", 7))))
