@@ -314,6 +314,11 @@ __global__ __launch_bounds__(kBlockX3) void linear_x3_kernel(const float* __rest
 // 48 % of those cycles (SQ_VALU_MFMA_BUSY_CYCLES = 96 M MFMAs x 16), no LDS bank conflicts; with X confined to an
 // 8 MB footprint (every row tile reading the same 64 tiles: a measurement build) 1.42 / 1.04 ms -- memory latency is
 // worth 10-15 %, a second chunk of prefetch does not fit 168 registers.
+// Also built and measured, not kept: a "ping-pong" form -- one persistent 512-thread workgroup per CU on 256 x 128 tiles,
+// two chunk buffers in LDS (144 KB), the two waves of a SIMD splitting the next chunk and multiplying the current one in
+// opposite order, one barrier per chunk, the fetch two chunks ahead (254 registers): 1.85 ms against this form's 1.55
+// (matrix cores busy 35 %, vector ALU 32 %, i.e. the two jobs did NOT overlap, whichever pair of waves was given the
+// opposite order); three independent workgroups per CU interleave better than two hand-paired waves.
 constexpr int kTileR = 128, kTileC = 128;
 constexpr int kBlockT = 256;
 using f32x2 = __attribute__((ext_vector_type(2))) float;

@@ -1830,6 +1830,7 @@ def test_linear_f32_on_bf16_planes(dev, lpg_options, n, k, m, ldx, km, act, bias
     (20011, 128, 128, 160, "relu", True),                # padded rows of X
     (4099, 64, 384, 64, "tanh", True),                   # three strips, two chunks
     (129, 32, 128, 32, None, True),                      # one chunk; the second row tile holds a single row
+    (150_001, 64, 128, 64, "relu", True),                # 1172 row tiles
 ])
 def test_linear_f32_on_bf16_planes_tiled(dev, lpg_options, n, k, m, ldx, act, bias):
     """the tiled form of the bf16-plane linear (linear_x3 = 2: 128 x 128 output tiles, X and W split once per chunk into
