@@ -438,6 +438,19 @@ int cu_count() {
   return cus;
 }
 
+// workgroups per column strip.  All strips must be RESIDENT TOGETHER: with cus * per_cu workgroups per strip the grid's
+// second strip only started when the first had finished, and X came from HBM once per strip (bf16 256 -> 256: 2.07 GB
+// fetched for 1.02 GB of X, profiles/r03/linear_wres_traffic.txt).  cus * per_cu / strips of them, a multiple of 8, put
+// workgroup (i, strip 0) and (i, strip 1) -- the same row tiles at the same time -- on one XCD (ids i and i + gx), so
+// the second reader finds the rows in that XCD's L2 (10 M rows: 7.1 GB fetched for 5.1 GB of X -- the pairs drift apart
+// over a long launch; cutting the rows into one launch per 2^18 .. 2^20 rows to re-align them cost more than it returned).
+inline int64_t strip_grid_x(int per_cu, unsigned gy, int64_t n_tiles, int waves) {
+  int64_t gx = static_cast<int64_t>(cu_count()) * per_cu / (gy < 1 ? 1 : gy);
+  if (gy > 1 && gx >= 8) gx -= gx % 8;
+  gx = std::max<int64_t>(gx, 1);
+  return std::min<int64_t>(gx, ceil_div(n_tiles, waves));
+}
+
 template <typename T, int NT, int PG, int ACT>
 int launch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float* bias, T* y, int64_t ldy, int64_t n,
                 int k, int m, int y_vec, int variant, hipStream_t st) {
@@ -451,7 +464,7 @@ int launch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float* b
       constexpr size_t lds = (static_cast<size_t>(NT) * 32 * LD + (kBlock3 / 64) * 16 * static_cast<size_t>(LDO)) * sizeof(T);
       if (!per_cu[2]) per_cu[2] = blocks_per_cu(kern, lds, kBlock3);
       LPG_REQUIRE(per_cu[2] > 0, "linear (W-resident): occupancy query failed");
-      const int64_t gx = std::min<int64_t>(static_cast<int64_t>(cu_count()) * per_cu[2], ceil_div(n_tiles, kBlock3 / 64));
+      const int64_t gx = strip_grid_x(per_cu[2], gy, n_tiles, kBlock3 / 64);
       hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx), gy), dim3(kBlock3), lds, st, x, ldx, w, w_is_km, bias, y,
                          ldy, n, k, m, n_tiles, y_vec);
       return 1;
@@ -462,7 +475,7 @@ int launch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float* b
     constexpr size_t lds = static_cast<size_t>(NT) * 32 * LD * sizeof(T);
     if (!per_cu[1]) per_cu[1] = blocks_per_cu(kern, lds);
     LPG_REQUIRE(per_cu[1] > 0, "linear (W-resident): occupancy query failed");
-    const int64_t gx = std::min<int64_t>(static_cast<int64_t>(cu_count()) * per_cu[1], ceil_div(n_tiles, kBlock / 64));
+    const int64_t gx = strip_grid_x(per_cu[1], gy, n_tiles, kBlock / 64);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx), gy), dim3(kBlock), lds, st, x, ldx, w, w_is_km, bias, y,
                        ldy, n, k, m, n_tiles);
   } else if constexpr (PG != 20) {
@@ -470,7 +483,7 @@ int launch_wres(const T* x, int64_t ldx, const T* w, int w_is_km, const float* b
     constexpr size_t lds = (static_cast<size_t>(NT) * 32 * LD + 4 * 32 * static_cast<size_t>(LD > LDO ? LD : LDO)) * sizeof(T);
     if (!per_cu[0]) per_cu[0] = blocks_per_cu(kern, lds);
     LPG_REQUIRE(per_cu[0] > 0, "linear (W-resident): occupancy query failed");
-    const int64_t gx = std::min<int64_t>(static_cast<int64_t>(cu_count()) * per_cu[0], ceil_div(n_tiles, kBlock / 64));
+    const int64_t gx = strip_grid_x(per_cu[0], gy, n_tiles, kBlock / 64);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx), gy), dim3(kBlock), lds, st, x, ldx, w, w_is_km, bias, y,
                        ldy, n, k, m, n_tiles, y_vec);
   }
