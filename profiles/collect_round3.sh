@@ -18,6 +18,7 @@ python profiles/spmm_mid_graph.py > $OUT/spmm_mid_graph.log 2>&1
 python profiles/degree_ones_probe.py > $OUT/degree_ones_probe.log 2>&1
 python profiles/kernel_zoo.py > $OUT/kernel_zoo.log 2>&1
 python profiles/linear_x3_tiled.py > $OUT/linear_x3_tiled.log 2>&1
+python profiles/linear_bf16_shapes.py > $OUT/linear_bf16_shapes.log 2>&1
 LPG_LIB_VARIANT=tuning python profiles/seal_conv_phases.py > $OUT/seal_conv_phases.log 2>&1
 echo "[collect] scripts done"
 cd /tmp && export TMPDIR=/tmp
