@@ -444,6 +444,9 @@ int cu_count() {
 // workgroup (i, strip 0) and (i, strip 1) -- the same row tiles at the same time -- on one XCD (ids i and i + gx), so
 // the second reader finds the rows in that XCD's L2 (10 M rows: 7.1 GB fetched for 5.1 GB of X -- the pairs drift apart
 // over a long launch; cutting the rows into one launch per 2^18 .. 2^20 rows to re-align them cost more than it returned).
+// Also measured, not kept: BOTH strips resident in one 512-thread workgroup (2 x 66 KB of W, 8-row output slices), waves w
+// and w + 4 taking the same row tiles -- X reaches the CU exactly once, but only four row tiles are in flight per CU
+// instead of eight: 3.11 ms at 10 M rows against 2.55 (the kernel lives on bytes in flight, not on fetch volume).
 inline int64_t strip_grid_x(int per_cu, unsigned gy, int64_t n_tiles, int waves) {
   int64_t gx = static_cast<int64_t>(cu_count()) * per_cu / (gy < 1 ? 1 : gy);
   if (gy > 1 && gx >= 8) gx -= gx % 8;

@@ -1882,6 +1882,8 @@ def test_linear_f32_on_bf16_planes_tiled(dev, lpg_options, n, k, m, ldx, act, bi
     ("bf16", 20011, 134, 32, 136, True, "tanh", False),     # SEAL's first layer: [onehot(6) || 128], padded rows
     ("bf16", 16385, 32, 32, 32, True, None, True),
     ("bf16", 20011, 100, 20, 104, False, "relu", True),
+    ("bf16", 20011, 256, 256, 256, False, None, True),      # two column strips (variant 3), co-resident workgroups paired on one XCD
+    ("bf16", 20011, 200, 200, 208, True, "relu", True),     # ... with ragged k and a ragged second strip
 ])
 def test_linear_persistent_w_resident(dev, lpg_options, variant, dtype, n, k, m, ldx, km, act, bias):
     """the persistent W-resident kernels (csrc/linear_wres.hip), taken automatically from 16384 rows (49152 for fp32
