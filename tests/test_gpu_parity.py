@@ -2635,6 +2635,26 @@ def test_graph_norm_weighted_table_and_conv1_on_table_rows(dev, tw, monkeypatch)
             assert np.abs(o - x).max() <= 2 * TOL * scale, np.abs(o - x).max() / scale
 
 
+def test_one_wl_stage_degree_beyond_the_table_raises(dev):
+    """a degree larger than the embedding table (the reference's nn.Embedding raises IndexError there): the compacted-table
+    path of twowl._one_wl_stage must raise as well, not gather a neighbouring row"""
+    from lpgnn_amd import twowl
+    from oracle import twowl_int
+    rng = np.random.default_rng(3)
+    N, E = 30_000, 90_000
+    und = rng.integers(0, N, size=(2, E))
+    und[0, :6000] = 7
+    pe = torch.from_numpy(twowl_int.double(und)).to(dev)
+    deg = twowl.degree(pe, N)
+    torch.manual_seed(0)
+    mod = twowl.LocalWLNet(int(deg.max()) - 100, channels_1wl=32, channels_2wl=16).to(dev).eval()
+    assert mod.emb[0].weight.shape[0] > twowl._TABLE_COMPACT_MIN
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            mod._one_wl_stage(deg, pe)
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("n", [1022 * 32768 + 5, 1023 * 32768 + 5])
 def test_degree_partition_bucket_limit(dev, n, monkeypatch):
     """the chunk-local partition of csrc/degree.hip holds one bucket per 32 K nodes and at most 1023 of them (thread t
