@@ -150,7 +150,9 @@ __device__ unsigned long long g_conv_phase[12];
 #endif
 
 template <int NP, typename TIN, bool CAT, bool K1>
-__global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : 2) void seal_conv_t2_kernel(
+// (fp32 with BOTH the concat and the fused head -- a combination no caller in the package uses -- needs 260 registers: one
+// workgroup per CU is declared for it instead of letting the compiler miss a bound of two)
+__global__ __launch_bounds__(kConvBlock, (NP == 1 && !CAT) ? 3 : ((NP == 3 && CAT && K1) ? 1 : 2)) void seal_conv_t2_kernel(
     const int64_t* __restrict__ node_off, const int32_t* __restrict__ first, const uint32_t* __restrict__ adj_bits,
     const TIN* __restrict__ h1, int64_t ldh, const TIN* __restrict__ w2, const TIN* __restrict__ w3,
     const TIN* __restrict__ w4, TIN* __restrict__ cat, int64_t ldc, float* __restrict__ key,
